@@ -1,0 +1,205 @@
+"""The oracle (oracle/subpixal_oracle.py) against every golden vector produced
+by the reference (tests/golden/gen_goldens.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import datagen
+from oracle import subpixal_oracle as orc
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_find_displacement_goldens(golden_dir):
+    g = _load(golden_dir, 'find_displacement.npz')
+    n = len(g['dx'])
+    assert n >= 300
+    worst = 0.0
+    for i in range(n):
+        ims = datagen.dither_set(int(g['ny'][i]), int(g['nx'][i]), g['tx'][i],
+                                 g['ty'][i], g['sigma'][i], g['amp'][i],
+                                 datagen.DTYPES[int(g['dtype'][i])],
+                                 int(g['noise_seed'][i]), g['noise_level'][i],
+                                 int(g['zero_mode'][i]))
+        # regenerated inputs are the ones the generator saw
+        s = sum(float(np.sum(im, dtype=np.float64)) for im in ims)
+        assert s == g['in_sum'][i]
+        dx, dy, icc, _ = orc.find_displacement(
+            *ims, cc_type=datagen.CC_TYPES[int(g['cc_type'][i])],
+            full_output=True)
+        worst = max(worst, abs(dx - g['dx'][i]), abs(dy - g['dy'][i]))
+        assert int(np.argmax(icc)) == int(g['icc_argmax'][i])
+        assert float(np.max(icc)) == g['icc_max'][i]
+        assert np.sum(icc, dtype=np.float64) == pytest.approx(g['icc_sum'][i], rel=1e-12, abs=1e-12)
+    assert worst < 1e-10, worst
+
+
+def test_find_displacement_full_output(golden_dir):
+    g = _load(golden_dir, 'find_displacement.npz')
+    for tag in 'ab':
+        ny, nx, ct = (int(v) for v in g['full_%s_shape' % tag])
+        ims = datagen.dither_set(ny, nx, 0.37, -0.81, 2.0, 1.3, np.float32)
+        dx, dy, icc, ccs = orc.find_displacement(
+            *ims, cc_type=datagen.CC_TYPES[ct], full_output=True)
+        assert icc.dtype == g['full_%s_icc' % tag].dtype
+        np.testing.assert_array_equal(icc, g['full_%s_icc' % tag])
+        np.testing.assert_array_equal(np.stack(ccs), g['full_%s_ccs' % tag])
+        np.testing.assert_allclose([dx, dy], g['full_%s_dxdy' % tag], atol=1e-12)
+
+
+def test_known_answers_from_survey():
+    # SURVEY.md 8c, float64 inputs
+    kats = [
+        (32, 2.0, 0.37, -0.81, 'CC', (0.3715581494418565, -0.8122669177908612)),
+        (32, 2.0, 0.37, -0.81, 'ZNCC', (0.37175024205009777, -0.7978068270598211)),
+        (64, 4.0, 1.234, -2.345, 'CC', (1.2334906030971169, -2.345338289871332)),
+        (64, 4.0, 1.234, -2.345, 'ZNCC', (1.2066915371895917, -2.3232555703747977)),
+        (128, 4.0, 2.5, 2.5, 'CC', (2.499999999992866, 2.5000000000015206)),
+    ]
+    for n, s, tx, ty, ct, exp in kats:
+        ims = datagen.dither_set(n, n, tx, ty, s, 1.0, np.float64)
+        got = orc.find_displacement(*ims, cc_type=ct)
+        np.testing.assert_allclose(got, exp, atol=1e-10)
+
+
+def test_pair_u1_goldens(golden_dir):
+    g = _load(golden_dir, 'pair_u1.npz')
+    worst = 0.0
+    worst64 = 0.0
+    for i in range(len(g['dx'])):
+        n = int(g['n'][i])
+        ref, img = datagen.pair_set(n, n, g['tx'][i], g['ty'][i], g['sigma'][i],
+                                    g['amp'][i], datagen.DTYPES[int(g['dtype'][i])])
+        dx, dy = orc.pair_shift_u1(ref, img)
+        worst = max(worst, abs(dx - g['dx'][i]), abs(dy - g['dy'][i]))
+        # the float64 definition of the pair mode at U=1 (own FFT, own window)
+        ddx, ddy = orc.xcorr_refine(ref, img, upsample=1)
+        worst64 = max(worst64, abs(ddx - g['dx'][i]), abs(ddy - g['dy'][i]))
+    assert worst < 1e-10, worst
+    # float64 restatement vs the reference's float32 FFT on float32 inputs
+    assert worst64 < 2e-5, worst64
+
+
+def test_find_peak_goldens(golden_dir):
+    g = _load(golden_dir, 'find_peak.npz')
+    meta = json.loads(str(g['meta_json']))
+    assert len(meta['cases']) >= 500
+    worst = 0.0
+    for k, case in enumerate(meta['cases']):
+        kw = {a: (tuple(v) if isinstance(v, list) else v)
+              for a, v in case['kwargs'].items()}
+        mask = g['mask_%03d' % k] if case['has_mask'] else None
+        got = orc.find_peak(g['img_%03d' % k], mask=mask, **kw)
+        exp = case['expected']
+        err = max(abs(got[0] - exp[0]), abs(got[1] - exp[1]))
+        assert err < 1e-9, (k, kw, got, exp)
+        worst = max(worst, err)
+    for case in meta['errors']:
+        kw = {a: (tuple(v) if isinstance(v, list) else v)
+              for a, v in case['kwargs'].items()}
+        if case['raises'] is None:
+            orc.find_peak(g['img_err'], **kw)
+        else:
+            with pytest.raises(Exception) as ei:
+                orc.find_peak(g['img_err'], **kw)
+            assert type(ei.value).__name__ == case['raises']
+
+
+def test_find_peak_constant_operator(golden_dir):
+    """c = pinv(V) d in box-relative coordinates == centroid.py's lstsq."""
+    g = _load(golden_dir, 'find_peak.npz')
+    meta = json.loads(str(g['meta_json']))
+    checked = 0
+    for k, case in enumerate(meta['cases']):
+        kw = case['kwargs']
+        img = g['img_%03d' % k]
+        if case['has_mask'] or 'xmax' in kw or min(img.shape) < 5:
+            continue
+        if kw.get('peak_fit_box', 5) != 5:
+            continue
+        x, y, st = orc.find_peak_5x5_all(img)
+        exp = case['expected']
+        assert abs(x - exp[0]) < 1e-9 and abs(y - exp[1]) < 1e-9, (k, x, y, exp)
+        st2 = []
+        orc.find_peak(img, peak_fit_box=5, peak_search_box='all', _status=st2)
+        assert st == st2[-1]
+        checked += 1
+    assert checked > 50
+
+
+def test_py2round(golden_dir):
+    g = _load(golden_dir, 'find_peak.npz')
+    xs = g['py2round_x']
+    np.testing.assert_array_equal(orc.py2round(xs), g['py2round_array'])
+    for v, e in zip(xs, g['py2round_scalar']):
+        assert float(orc.py2round(float(v))) == e
+
+
+def test_xcorr_same_matches_definition():
+    rng = np.random.default_rng(5)
+    for shape in [(6, 6), (7, 9), (8, 5), (12, 12)]:
+        a = rng.standard_normal(shape)
+        b = rng.standard_normal(shape)
+        np.testing.assert_allclose(orc.xcorr_same(a, b),
+                                   orc.xcorr_same_direct(a, b), atol=1e-10)
+        # pair mode U=1 == flipped 'same' window
+        np.testing.assert_allclose(orc.upsampled_cc(a, b, 1),
+                                   orc.xcorr_same_direct(a, b)[::-1, ::-1],
+                                   atol=1e-10)
+
+
+def test_upsampled_cc_consistency():
+    """Full-grid Fourier upsampling == windowed matrix DFT; every U-th sample
+    is the U=1 image."""
+    rng = np.random.default_rng(6)
+    ref, img = datagen.pair_set(32, 32, 0.7, -1.3, 2.5, 1.0, np.float64)
+    ref = ref + 0.01 * rng.standard_normal(ref.shape)
+    for up in (2, 3, 10):
+        fine = orc.upsampled_cc(ref, img, up)
+        np.testing.assert_allclose(fine[::up, ::up], orc.upsampled_cc(ref, img, 1),
+                                   atol=1e-9)
+        qy = np.arange(5 * up, 9 * up)
+        qx = np.arange(20 * up + 1, 23 * up)
+        np.testing.assert_allclose(orc.upsampled_cc_window(ref, img, up, qy, qx),
+                                   fine[np.ix_(qy, qx)], atol=1e-9)
+    for up in (2, 10):
+        a = orc.xcorr_refine(ref, img, up, full_grid=True)
+        b = orc.xcorr_refine(ref, img, up, full_grid=False)
+        np.testing.assert_allclose(a, b, atol=1e-9)
+
+
+def test_pair_u2_reproduces_reference_on_dithers(golden_dir):
+    """pair mode at U=2 == the reference's 5-image interlace on
+    analytic half-pixel dithers of well-sampled spots."""
+    g = _load(golden_dir, 'bench_parity.npz')
+    for n, tol in ((32, 1e-4), (64, 2e-5)):   # float32 inputs; n=32 spots are clipped by the tile
+        p = g['n%d_params' % n]
+        exp = g['n%d_dxdy' % n]
+        worst = 0.0
+        for k in range(16):
+            ref, img = datagen.pair_set(n, n, p[k, 0], p[k, 1], p[k, 2], p[k, 3],
+                                        np.float32)
+            got = orc.xcorr_refine(ref, img, upsample=2)
+            worst = max(worst, np.max(np.abs(np.array(got) - exp[k])))
+        assert worst < tol, (n, worst)
+
+
+def test_pair_u10_within_1e3_of_reference(golden_dir):
+    """north_star tolerance: U=10 pair mode within 1e-3 px of the reference
+    5-image path for sigma >= 4 px (n >= 64)."""
+    g = _load(golden_dir, 'bench_parity.npz')
+    p = g['n64_params']
+    exp = g['n64_dxdy']
+    worst = 0.0
+    for k in range(24):
+        ref, img = datagen.pair_set(64, 64, p[k, 0], p[k, 1], p[k, 2], p[k, 3],
+                                    np.float32)
+        got = orc.xcorr_refine(ref, img, upsample=10)
+        worst = max(worst, np.max(np.abs(np.array(got) - exp[k])))
+        # and it is closer to the truth than the reference's own fit bias
+        assert np.max(np.abs(np.array(got) - p[k, :2])) < 2e-4
+    assert worst < 1e-3, worst
