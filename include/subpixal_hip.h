@@ -1,0 +1,147 @@
+/*
+ * subpixal_hip.h -- C ABI of libsubpixal_hip.so: the MI355X (gfx950) replacement
+ * for subpixal's per-cutout cross-correlation + sub-pixel peak refinement.
+ *
+ * The reference (spacetelescope/subpixal) is pure Python and has NO native/FFI
+ * boundary; the calls below are what a ctypes binding placed at its hot-path
+ * call sites would bind (INTEGRATION.md shows the stub):
+ *
+ *   spx_find_displacement5_f32  <-  cc.find_displacement(ref, im00, im10, im01,
+ *                                   im11, cc_type, full_output)   subpixal/cc.py:21-95,
+ *                                   called once per source at subpixal/align.py:682-685;
+ *                                   here for a whole batch (the loop align.py:656-699
+ *                                   carries no state between sources).
+ *   spx_xcorr_refine_f32        <-  the pair / upsample=U form of the same path that
+ *                                   BASELINE.json measures (one fftconvolve, cc.py:114,
+ *                                   + find_peak, cc.py:86, on a U-times finer grid).
+ *   spx_find_peak_f64           <-  centroid.find_peak(image, xmax, ymax, peak_fit_box,
+ *                                   peak_search_box, mask)        subpixal/centroid.py:18-236.
+ *   spx_gather_cutouts_f32      <-  Cutout.__init__ slicing/fill  subpixal/cutout.py:737-755
+ *                                   + masked-pixel zeroing        subpixal/align.py:661.
+ *   spx_gen_gaussian_pairs_f32  --  synthetic workload generator (bench / tests only).
+ *
+ * Conventions
+ *   - All array pointers are DEVICE pointers owned by the caller (e.g. torch
+ *     tensors' data_ptr()), contiguous, row-major; nothing returned is owned by
+ *     the library.  `stream` is a hipStream_t (NULL = default stream).  Calls
+ *     enqueue work and return without synchronising.
+ *   - Return value 0 = OK, negative = SPX_E_* ; spx_last_error() gives the text
+ *     (thread-local).  Per-item degenerate cases (edge peak, no maximum ...) are
+ *     NOT call failures: they are reported in `out_status` (SPX_ST_*), exactly
+ *     the early returns of centroid.py:171-172, 218-225, 230-236.
+ *   - Constant tables (twiddles, interpolation kernels) are built on first use
+ *     per device and upsampling factor; call spx_prepare() up front if the launch
+ *     must not allocate (stream capture).
+ *   - One host thread per device at a time.
+ */
+#ifndef SUBPIXAL_HIP_H
+#define SUBPIXAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPX_ABI_VERSION 1
+
+/* cc_type (cc.py:107-111; anything else than NCC/ZNCC means plain CC) */
+#define SPX_CC 0
+#define SPX_NCC 1
+#define SPX_ZNCC 2
+
+/* per-item status */
+#define SPX_ST_OK 0        /* quadratic vertex accepted                                  */
+#define SPX_ST_EDGE 1      /* arg-max in row/column 0 -> integer peak (centroid.py:171)  */
+#define SPX_ST_NOMAX 2     /* no maximum -> centre of the fit box   (centroid.py:218)    */
+#define SPX_ST_OUTSIDE 3   /* vertex outside image -> integer peak  (centroid.py:230)    */
+#define SPX_ST_WINDOW 4    /* fine peak not bracketed by the refinement window           */
+#define SPX_ST_FEWPTS 5    /* find_peak: fewer than 6 usable points (centroid.py:160,186,202) */
+
+/* error codes */
+#define SPX_E_ARG (-1)        /* bad argument                              */
+#define SPX_E_SHAPE (-2)      /* cutout shape / upsample not supported     */
+#define SPX_E_HIP (-3)        /* HIP runtime error                         */
+#define SPX_E_WORKSPACE (-4)  /* workspace missing or too small            */
+
+/* largest cutout side and upsampling factor the kernels accept */
+#define SPX_MAX_SIDE 64
+#define SPX_MAX_UPSAMPLE 59
+
+int spx_abi_version(void);
+int spx_device_count(void);
+/* select `device` for this process/thread and build its constant tables */
+int spx_init(int device);
+/* build the tables for `upsample` now (so later launches do not allocate) */
+int spx_prepare(int upsample);
+const char* spx_last_error(void);
+
+/* Bytes of scratch the batched calls need (0 when none). */
+size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx);
+
+/*
+ * Pair mode.  ref, img: float32 [nbatch][ny][nx].  For every pair: linear
+ * cross-correlation on the zero-padded 128x128 grid, arg-max over the flipped
+ * 'same' window, U-times trigonometric upsampling around it, 5x5 quadratic fit
+ * (find_peak(., 5, 'all')), shift = peak/U - (n-1)//2.
+ *   out_dxdy   : float64 [nbatch][2]  (dx, dy)
+ *   out_status : int32   [nbatch]     SPX_ST_* ; may be NULL
+ * 5 <= ny, nx <= SPX_MAX_SIDE; 1 <= upsample <= SPX_MAX_UPSAMPLE.
+ */
+int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
+                         int upsample, int cc_type, double* out_dxdy, int32_t* out_status,
+                         void* stream);
+
+/*
+ * Reference mode (cc.find_displacement).  ref: float32 [nbatch][ny][nx];
+ * im4: float32 [nbatch][4][ny][nx] in the order image00, image10, image01,
+ * image11.  out_icc: float32 [nbatch][2ny][2nx] interlaced cross-correlation
+ * images (full_output=True), or NULL, in which case `workspace` of
+ * spx_workspace_bytes_displacement5() bytes must be given.
+ * 3 <= ny, nx <= SPX_MAX_SIDE.
+ */
+int spx_find_displacement5_f32(const float* ref, const float* im4, int64_t nbatch, int ny,
+                               int nx, int cc_type, double* out_dxdy, int32_t* out_status,
+                               float* out_icc, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
+/*
+ * General find_peak (centroid.py:18-236), one image per workgroup.
+ *   image : float64 [nbatch][ny][nx]
+ *   mask  : uint8   [nbatch][ny][nx] (non-zero = good pixel) or NULL
+ *   guess : float64 [nbatch][2] (xmax, ymax) or NULL (search the whole image)
+ *   fit box (fit_wx, fit_wy) >= 1; search box (search_wx, search_wy), both 0 =
+ *   no brute-force search ('off'/None); ignored when guess is NULL.
+ *   out_xy : float64 [nbatch][2]; out_status int32 [nbatch] or NULL.
+ */
+int spx_find_peak_f64(const double* image, const uint8_t* mask, const double* guess,
+                      int64_t nbatch, int ny, int nx, int fit_wx, int fit_wy, int search_wx,
+                      int search_wy, double* out_xy, int32_t* out_status, void* stream);
+
+/*
+ * Cutout packing: gathers nbatch windows out of a frame into fixed tiles.
+ *   frame : float32 [fny][fnx];  fmask: uint8 [fny][fnx] non-zero = bad pixel, or NULL
+ *   boxes : int32 [nbatch][4] = (x0, y0, width, height), window may overhang the frame
+ *   tiles : float32 [nbatch][tny][tnx]; pixels outside the window/frame, masked
+ *           or non-finite are written as `fill` (cutout.py:737,755; align.py:661 uses 0)
+ */
+int spx_gather_cutouts_f32(const float* frame, const uint8_t* fmask, int fny, int fnx,
+                           const int32_t* boxes, int64_t nbatch, int tny, int tnx, float fill,
+                           float* tiles, void* stream);
+
+/*
+ * Synthetic Gaussian-spot pairs: pair k = first_index + i has
+ * tx, ty ~ U(-max_shift, max_shift), sigma ~ U(sigma_lo, sigma_hi), amplitude ~
+ * U(0.5, 2) from a counter-based generator keyed by (seed, k); ref has the spot
+ * at the tile centre, img at centre + (tx, ty).  truth_dxdy float64 [nbatch][2]
+ * (may be NULL).
+ */
+int spx_gen_gaussian_pairs_f32(uint64_t seed, int64_t first_index, int64_t nbatch, int n,
+                               float sigma_lo, float sigma_hi, float max_shift, float* ref,
+                               float* img, double* truth_dxdy, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUBPIXAL_HIP_H */

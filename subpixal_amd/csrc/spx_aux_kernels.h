@@ -1,0 +1,335 @@
+// spx_aux_kernels.h -- kernels either side of the cross-correlation hot path:
+//   find_peak_kernel      centroid.find_peak in full generality (centroid.py:18-236)
+//   gather_cutouts_kernel frame -> fixed tiles (cutout.py:737-755, align.py:661)
+//   gen_pairs_kernel      synthetic Gaussian-spot pairs for bench / tests
+// Needs spx_rt_hip.h (or the CPU harness) and spx_kernels.h first.
+#pragma once
+
+namespace spx {
+
+constexpr int kPeakMaxFitPoints = 1024;
+
+// ---------------------------------------------------------------------------
+// counter-based generator: splitmix64 stream keyed by (seed, pair index).
+// subpixal_amd/synth.py implements the same arithmetic with numpy uint64.
+// ---------------------------------------------------------------------------
+SPX_DEVICE uint64_t splitmix_next(uint64_t& z) {
+    z += 0x9E3779B97F4A7C15ull;
+    uint64_t r = z;
+    r = (r ^ (r >> 30)) * 0xBF58476D1CE4E5B9ull;
+    r = (r ^ (r >> 27)) * 0x94D049BB133111EBull;
+    return r ^ (r >> 31);
+}
+SPX_DEVICE double splitmix_uniform(uint64_t& z) {
+    return (double)(splitmix_next(z) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+SPX_TKERNEL(256)
+void gen_pairs_kernel(uint64_t seed, int64_t first_index, int64_t nbatch, int n, float sigma_lo,
+                      float sigma_hi, float max_shift, float* __restrict__ ref,
+                      float* __restrict__ img, double* __restrict__ truth) {
+    const int tid = rt::thread_id();
+    const int64_t npx = (int64_t)n * n;
+    for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
+        uint64_t z = seed + (uint64_t)(first_index + p + 1) * 0xD1342543DE82EF95ull;
+        const double tx = (2.0 * splitmix_uniform(z) - 1.0) * (double)max_shift;
+        const double ty = (2.0 * splitmix_uniform(z) - 1.0) * (double)max_shift;
+        const double sg = (double)sigma_lo + splitmix_uniform(z) * (double)(sigma_hi - sigma_lo);
+        const double am = 0.5 + 1.5 * splitmix_uniform(z);
+        const float c = 0.5f * (float)(n - 1);
+        const float cx = c + (float)tx, cy = c + (float)ty;
+        const float inv = -0.5f / ((float)sg * (float)sg);
+        const float amp = (float)am;
+        for (int64_t i = tid; i < npx; i += 256) {
+            const float y = (float)(i / n), x = (float)(i % n);
+            const float r2 = (x - c) * (x - c) + (y - c) * (y - c);
+            const float i2 = (x - cx) * (x - cx) + (y - cy) * (y - cy);
+            ref[p * npx + i] = amp * __builtin_expf(r2 * inv);
+            img[p * npx + i] = amp * __builtin_expf(i2 * inv);
+        }
+        if (truth && tid == 0) {
+            truth[2 * p] = tx;
+            truth[2 * p + 1] = ty;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// cutout packing.  boxes[b] = (x0, y0, w, h) in frame pixels.  Inside the box:
+// the frame pixel, or `fill` where the box overhangs the frame, the pixel is
+// flagged in fmask, or it is not finite (cutout.py:737-755 + align.py:661).
+// Outside the box (tile padding): 0, which leaves the linear cross-correlation
+// unchanged.
+// ---------------------------------------------------------------------------
+SPX_TKERNEL(256)
+void gather_cutouts_kernel(const float* __restrict__ frame, const uint8_t* __restrict__ fmask,
+                           int fny, int fnx, const int32_t* __restrict__ boxes, int64_t nbatch,
+                           int tny, int tnx, float fill, float* __restrict__ tiles) {
+    const int64_t total = nbatch * tny * tnx;
+    const int64_t step = rt::grid_size() * 256;
+    for (int64_t i = rt::block_id() * 256 + rt::thread_id(); i < total; i += step) {
+        const int tx = (int)(i % tnx);
+        const int ty = (int)((i / tnx) % tny);
+        const int64_t b = i / ((int64_t)tnx * tny);
+        const int x0 = boxes[4 * b], y0 = boxes[4 * b + 1];
+        const int w = boxes[4 * b + 2], h = boxes[4 * b + 3];
+        float v = 0.0f;
+        if (tx < w && ty < h) {
+            const int fx = x0 + tx, fy = y0 + ty;
+            v = fill;
+            if (fx >= 0 && fx < fnx && fy >= 0 && fy < fny) {
+                const float f = frame[(int64_t)fy * fnx + fx];
+                const bool bad = (fmask && fmask[(int64_t)fy * fnx + fx]) || !(f - f == 0.0f);
+                if (!bad) v = f;
+            }
+        }
+        tiles[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// general find_peak
+// ---------------------------------------------------------------------------
+SPX_DEVICE bool better_d(double v, int i, double bv, int bi) {
+    return (v > bv) || (v == bv && i < bi);
+}
+
+// workgroup arg-max of (double, int); red_d/red_i: LDS double[4]/int[4]
+SPX_DEVICE void block_argmax_d(double* red_d, int* red_i, double& v, int& idx) {
+    const int tid = rt::thread_id();
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = rt::shfl_xor(v, m);
+        const int oi = rt::shfl_xor(idx, m);
+        if (better_d(ov, oi, v, idx)) { v = ov; idx = oi; }
+    }
+    if ((tid & 63) == 0) { red_d[tid >> 6] = v; red_i[tid >> 6] = idx; }
+    rt::block_sync();
+    v = red_d[0];
+    idx = red_i[0];
+    for (int w = 1; w < kThreads / 64; ++w)
+        if (better_d(red_d[w], red_i[w], v, idx)) { v = red_d[w]; idx = red_i[w]; }
+    rt::block_sync();
+}
+
+// utils.py:144-161
+SPX_DEVICE double py2round(double x) { return x >= 0.0 ? floor(x + 0.5) : ceil(x - 0.5); }
+
+SPX_DEVICE int imin(int a, int b) { return a < b ? a : b; }
+SPX_DEVICE int imax2(int a, int b) { return a > b ? a : b; }
+
+// Minimum-norm least squares  min |A c - d|  for the N x 6 design matrix held
+// column-major in LDS (acol[j*N + i]), by one-sided (Hestenes) Jacobi SVD, run by
+// wave 0.  Singular values <= eps*max(N,6)*s_max are dropped, as
+// numpy.linalg.lstsq(rcond=None) does at centroid.py:207 (this reproduces its
+// minimum-norm answers on rank-deficient boxes, e.g. a 2x3 fit box).
+// vmat: LDS double[36]; coef: LDS double[6] (result).
+SPX_DEVICE void jacobi_lstsq_wave0(double* acol, const double* dvec, int N, double* vmat,
+                                   double* coef) {
+    const int lane = rt::thread_id() & 63;
+    if (lane < 6)
+        for (int j = 0; j < 6; ++j) vmat[lane * 6 + j] = (lane == j) ? 1.0 : 0.0;
+    rt::wave_sync();
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        int rotations = 0;
+        for (int p = 0; p < 5; ++p) {
+            for (int q = p + 1; q < 6; ++q) {
+                double al = 0.0, be = 0.0, ga = 0.0;
+                for (int i = lane; i < N; i += 64) {
+                    const double ap = acol[p * N + i], aq = acol[q * N + i];
+                    al += ap * ap;
+                    be += aq * aq;
+                    ga += ap * aq;
+                }
+                al = wave_sum(al);
+                be = wave_sum(be);
+                ga = wave_sum(ga);
+                if (ga == 0.0 || fabs(ga) <= 1e-15 * sqrt(al * be)) continue;
+                ++rotations;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta == 0.0)
+                                     ? 1.0
+                                     : (zeta > 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int i = lane; i < N; i += 64) {
+                    const double ap = acol[p * N + i], aq = acol[q * N + i];
+                    acol[p * N + i] = c * ap - s * aq;
+                    acol[q * N + i] = s * ap + c * aq;
+                }
+                if (lane < 6) {
+                    const double vp = vmat[lane * 6 + p], vq = vmat[lane * 6 + q];
+                    vmat[lane * 6 + p] = c * vp - s * vq;
+                    vmat[lane * 6 + q] = s * vp + c * vq;
+                }
+            }
+        }
+        if (rotations == 0) break;
+    }
+    rt::wave_sync();
+    double sig2[6], proj[6];
+    double smax2 = 0.0;
+    for (int j = 0; j < 6; ++j) {
+        double s2 = 0.0, pj = 0.0;
+        for (int i = lane; i < N; i += 64) {
+            const double a = acol[j * N + i];
+            s2 += a * a;
+            pj += a * dvec[i];
+        }
+        sig2[j] = wave_sum(s2);
+        proj[j] = wave_sum(pj);
+        if (sig2[j] > smax2) smax2 = sig2[j];
+    }
+    if (lane == 0) {
+        const double rcond = 2.220446049250313e-16 * (double)(N > 6 ? N : 6);
+        const double cut = rcond * sqrt(smax2);
+        for (int r = 0; r < 6; ++r) {
+            double x = 0.0;
+            for (int j = 0; j < 6; ++j)
+                if (sqrt(sig2[j]) > cut) x += vmat[r * 6 + j] * (proj[j] / sig2[j]);
+            coef[r] = x;
+        }
+    }
+    rt::wave_sync();
+}
+
+SPX_TKERNEL(256)
+void find_peak_kernel(const double* __restrict__ image, const uint8_t* __restrict__ mask,
+                      const double* __restrict__ guess, int64_t nbatch, int ny, int nx, int wx,
+                      int wy, int sbx, int sby, double* __restrict__ out,
+                      int* __restrict__ status) {
+    SPX_STATIC_LDS(double, acol, 6 * kPeakMaxFitPoints);
+    SPX_STATIC_LDS(double, dvec, kPeakMaxFitPoints);
+    SPX_STATIC_LDS(double, small, 64);     // [0..3] reduction, [8..43] V, [48..53] coef
+    SPX_STATIC_LDS(int, smalli, 16);       // [0..3] reduction, [8] point count
+    const int tid = rt::thread_id();
+    const int64_t npx = (int64_t)ny * nx;
+    for (int64_t b = rt::block_id(); b < nbatch; b += rt::grid_size()) {
+        const double* img = image + b * npx;
+        const uint8_t* msk = mask ? mask + b * npx : nullptr;
+        bool have_guess = guess != nullptr;
+        double rx = 0.0, ry = 0.0;
+        int st = ST_OK;
+        for (int pass = 0; pass < 2; ++pass) {
+            int imax, jmax;
+            double cx, cy;
+            bool expand = false;
+            if (!have_guess) {                                   // centroid.py:111-127
+                double bv = -__builtin_inf();
+                int bi = 0x7fffffff;
+                for (int64_t i = tid; i < npx; i += kThreads) {
+                    if (msk && !msk[i]) continue;
+                    const double v = img[i];
+                    if (better_d(v, (int)i, bv, bi)) { bv = v; bi = (int)i; }
+                }
+                block_argmax_d(small, smalli, bv, bi);
+                if (bi == 0x7fffffff) bi = 0;                    // nothing selectable
+                jmax = bi / nx;
+                imax = bi % nx;
+                cx = (double)imax;
+                cy = (double)jmax;
+            } else {                                             // centroid.py:129-156
+                cx = guess[2 * b];
+                cy = guess[2 * b + 1];
+                imax = (int)py2round(cx);
+                jmax = (int)py2round(cy);
+                if (sbx > 0) {
+                    const int x1 = imax2(0, imax - sbx / 2), x2 = imin(nx, x1 + sbx);
+                    const int y1 = imax2(0, jmax - sby / 2), y2 = imin(ny, y1 + sby);
+                    if (x1 < x2 && y1 < y2) {
+                        const int bw = x2 - x1, bh = y2 - y1;
+                        double bv = -__builtin_inf();
+                        int bi = 0x7fffffff;
+                        for (int i = tid; i < bw * bh; i += kThreads) {
+                            const double v = img[(int64_t)(y1 + i / bw) * nx + x1 + i % bw];
+                            if (better_d(v, i, bv, bi)) { bv = v; bi = i; }
+                        }
+                        block_argmax_d(small, smalli, bv, bi);
+                        if (bi == 0x7fffffff) bi = 0;
+                        imax = x1 + bi % bw;
+                        jmax = y1 + bi / bw;
+                        cx = (double)imax;
+                        cy = (double)jmax;
+                    }
+                    expand = (sbx != nx || sby != ny);
+                }
+            }
+            rx = cx; ry = cy;
+            if (wx * wy < 6) { st = ST_FEWPTS; break; }           // centroid.py:160-162
+            int x1 = imax2(0, imax - wx / 2), x2 = imin(nx, x1 + wx);   // :165-168
+            int y1 = imax2(0, jmax - wy / 2), y2 = imin(ny, y1 + wy);
+            if (imax == x1 || imax == x2 || jmax == y1 || jmax == y2) {  // :171-172
+                rx = (double)imax; ry = (double)jmax; st = ST_EDGE;
+                break;
+            }
+            if (x2 - x1 < wx) {                                   // :175-179
+                if (x1 == 0) x2 = imin(nx, x1 + wx);
+                if (x2 == nx) x1 = imax2(0, x2 - wx);
+            }
+            if (y2 - y1 < wy) {                                   // :180-184
+                if (y1 == 0) y2 = imin(ny, y1 + wy);
+                if (y2 == ny) y1 = imax2(0, y2 - wy);
+            }
+            if ((x2 - x1) * (y2 - y1) < 6) { st = ST_FEWPTS; break; }   // :186-188
+            // design matrix over the (masked) box, absolute coordinates: :191-204
+            const int bw = x2 - x1, bh = y2 - y1;
+            if (tid == 0) {
+                int n = 0;
+                for (int j = 0; j < bh; ++j)
+                    for (int i = 0; i < bw; ++i) {
+                        const int64_t g = (int64_t)(y1 + j) * nx + x1 + i;
+                        if (msk && !msk[g]) continue;
+                        dvec[n++] = img[g];
+                    }
+                smalli[8] = n;
+            }
+            rt::block_sync();
+            const int npts = smalli[8];
+            if (npts < 6) { st = ST_FEWPTS; rt::block_sync(); break; }
+            if (tid == 0) {
+                int n = 0;
+                for (int j = 0; j < bh; ++j)
+                    for (int i = 0; i < bw; ++i) {
+                        const int64_t g = (int64_t)(y1 + j) * nx + x1 + i;
+                        if (msk && !msk[g]) continue;
+                        const double x = (double)(x1 + i), y = (double)(y1 + j);
+                        acol[0 * npts + n] = 1.0;
+                        acol[1 * npts + n] = x;
+                        acol[2 * npts + n] = y;
+                        acol[3 * npts + n] = x * y;
+                        acol[4 * npts + n] = x * x;
+                        acol[5 * npts + n] = y * y;
+                        ++n;
+                    }
+            }
+            rt::block_sync();
+            if (tid < 64) jacobi_lstsq_wave0(acol, dvec, npts, small + 8, small + 48);
+            rt::block_sync();
+            const double c10 = small[49], c01 = small[50], c11 = small[51];
+            const double c20 = small[52], c02 = small[53];
+            rt::block_sync();
+            const double det = 4.0 * c02 * c20 - c11 * c11;           // :217-225
+            if (det <= 0.0 || ((c20 > 0.0 && c02 >= 0.0) || (c20 >= 0.0 && c02 > 0.0))) {
+                if (expand) { have_guess = false; continue; }
+                rx = (x1 + x2) / 2.0; ry = (y1 + y2) / 2.0; st = ST_NOMAX;
+                break;
+            }
+            const double xm = (c01 * c11 - 2.0 * c02 * c10) / det;    // :227-228
+            const double ym = (c10 * c11 - 2.0 * c01 * c20) / det;
+            if (xm > 0.0 && xm < nx - 1.0 && ym > 0.0 && ym < ny - 1.0) {   // :230-236
+                rx = xm; ry = ym; st = ST_OK;
+                break;
+            }
+            if (expand) { have_guess = false; continue; }
+            st = ST_OUTSIDE;
+            break;
+        }
+        if (tid == 0) {
+            out[2 * b] = rx;
+            out[2 * b + 1] = ry;
+            if (status) status[b] = st;
+        }
+        rt::block_sync();
+    }
+}
+
+}  // namespace spx

@@ -1,0 +1,246 @@
+// libsubpixal_hip.so -- C ABI (include/subpixal_hip.h) over the gfx950 kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC spx_capi.hip
+#include "spx_rt_hip.h"
+#include "spx_kernels.h"
+#include "spx_aux_kernels.h"
+#include "spx_tables.h"
+#include "../../include/subpixal_hip.h"
+
+#include <map>
+#include <mutex>
+#include <string>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    return fail(SPX_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define SPX_HIP(call)                                              \
+    do {                                                           \
+        hipError_t e__ = (call);                                   \
+        if (e__ != hipSuccess) return hip_fail(e__, #call);        \
+    } while (0)
+
+struct DeviceTables {
+    spx::cf* tw128 = nullptr;                 // w_128^j
+    std::map<int, float*> ktab;               // upsample -> [2][W][64]
+    int num_cu = 256;
+    bool lds_attr_set = false;
+};
+
+std::mutex g_mu;
+std::map<int, DeviceTables> g_dev;
+
+int current_tables(DeviceTables** out) {
+    int dev = 0;
+    SPX_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceTables& t = g_dev[dev];
+    if (!t.tw128) {
+        std::vector<float> tw = spx::host::make_twiddles(128);
+        void* p = nullptr;
+        SPX_HIP(hipMalloc(&p, tw.size() * sizeof(float)));
+        SPX_HIP(hipMemcpy(p, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+        t.tw128 = reinterpret_cast<spx::cf*>(p);
+        hipDeviceProp_t prop;
+        SPX_HIP(hipGetDeviceProperties(&prop, dev));
+        t.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    *out = &t;
+    return 0;
+}
+
+int ktab_for(DeviceTables* t, int upsample, const float** out) {
+    *out = nullptr;
+    const int wb = spx::host::window_blocks(upsample);
+    if (wb <= 0) return 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = t->ktab.find(upsample);
+    if (it == t->ktab.end()) {
+        std::vector<float> k = spx::host::make_ktab(128, upsample, 16 * wb);
+        void* p = nullptr;
+        SPX_HIP(hipMalloc(&p, k.size() * sizeof(float)));
+        SPX_HIP(hipMemcpy(p, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
+        it = t->ktab.emplace(upsample, reinterpret_cast<float*>(p)).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+template <typename K> int allow_lds(K kernel, int bytes) {
+    SPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return 0;
+}
+
+// workgroups per launch: enough to fill 256 CUs x 2 resident groups several times
+// over; the kernels grid-stride over the batch.
+unsigned grid_for(const DeviceTables* t, int64_t nbatch) {
+    const int64_t cap = (int64_t)t->num_cu * 32;
+    return (unsigned)(nbatch < cap ? nbatch : cap);
+}
+
+template <int WB>
+int launch_pair(const DeviceTables* t, const float* ref, const float* img, int64_t nbatch, int ny,
+                int nx, int U, int cc_type, const float* ktab, double* out, int32_t* status,
+                hipStream_t s) {
+    const int lds = spx::Lds<2>::total(16 * WB);
+    auto kern = spx::pair_kernel<2, WB>;
+    int rc = allow_lds(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid_for(t, nbatch)), dim3(spx::kThreads), lds, s, ref, img,
+                       nbatch, ny, nx, U, cc_type, t->tw128, ktab, out, status);
+    SPX_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spx_abi_version(void) { return SPX_ABI_VERSION; }
+
+const char* spx_last_error(void) { return g_err.c_str(); }
+
+int spx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int spx_init(int device) {
+    SPX_HIP(hipSetDevice(device));
+    DeviceTables* t = nullptr;
+    return current_tables(&t);
+}
+
+int spx_prepare(int upsample) {
+    if (spx::host::window_blocks(upsample) < 0)
+        return fail(SPX_E_SHAPE, "upsample must be in [1, 59]");
+    DeviceTables* t = nullptr;
+    int rc = current_tables(&t);
+    if (rc) return rc;
+    const float* k = nullptr;
+    return ktab_for(t, upsample, &k);
+}
+
+size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx) {
+    if (nbatch <= 0 || ny <= 0 || nx <= 0) return 0;
+    return (size_t)nbatch * 4u * (size_t)ny * (size_t)nx * sizeof(float);
+}
+
+int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
+                         int upsample, int cc_type, double* out_dxdy, int32_t* out_status,
+                         void* stream) {
+    if (nbatch < 0 || !out_dxdy || (nbatch > 0 && (!ref || !img)))
+        return fail(SPX_E_ARG, "null pointer or negative batch");
+    if (ny < 5 || nx < 5 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
+        return fail(SPX_E_SHAPE, "pair mode supports cutouts of 5..64 pixels per side");
+    const int wb = spx::host::window_blocks(upsample);
+    if (wb < 0) return fail(SPX_E_SHAPE, "upsample must be in [1, 59]");
+    if (nbatch == 0) return 0;
+    DeviceTables* t = nullptr;
+    int rc = current_tables(&t);
+    if (rc) return rc;
+    const float* ktab = nullptr;
+    rc = ktab_for(t, upsample, &ktab);
+    if (rc) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (wb) {
+    case 0: return launch_pair<0>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
+    case 1: return launch_pair<1>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
+    case 2: return launch_pair<2>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
+    case 3: return launch_pair<3>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
+    default: return launch_pair<4>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
+    }
+}
+
+int spx_find_displacement5_f32(const float* ref, const float* im4, int64_t nbatch, int ny,
+                               int nx, int cc_type, double* out_dxdy, int32_t* out_status,
+                               float* out_icc, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    if (nbatch < 0 || !out_dxdy || (nbatch > 0 && (!ref || !im4)))
+        return fail(SPX_E_ARG, "null pointer or negative batch");
+    if (ny < 3 || nx < 3 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
+        return fail(SPX_E_SHAPE, "5-image mode supports cutouts of 3..64 pixels per side");
+    if (nbatch == 0) return 0;
+    float* icc = out_icc;
+    if (!icc) {
+        if (!workspace || workspace_bytes < spx_workspace_bytes_displacement5(nbatch, ny, nx))
+            return fail(SPX_E_WORKSPACE, "out_icc is NULL and the workspace is too small");
+        icc = reinterpret_cast<float*>(workspace);
+    }
+    DeviceTables* t = nullptr;
+    int rc = current_tables(&t);
+    if (rc) return rc;
+    const int lds = spx::Lds<2>::total(0);
+    auto kern = spx::disp5_kernel<2>;
+    rc = allow_lds(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid_for(t, nbatch)), dim3(spx::kThreads), lds,
+                       reinterpret_cast<hipStream_t>(stream), ref, im4, nbatch, ny, nx, cc_type,
+                       t->tw128, icc, out_dxdy, out_status);
+    SPX_HIP(hipGetLastError());
+    return 0;
+}
+
+int spx_find_peak_f64(const double* image, const uint8_t* mask, const double* guess,
+                      int64_t nbatch, int ny, int nx, int fit_wx, int fit_wy, int search_wx,
+                      int search_wy, double* out_xy, int32_t* out_status, void* stream) {
+    if (nbatch < 0 || !out_xy || (nbatch > 0 && !image))
+        return fail(SPX_E_ARG, "null pointer or negative batch");
+    if (ny < 1 || nx < 1 || (int64_t)ny * nx > (int64_t)1 << 30)
+        return fail(SPX_E_SHAPE, "bad image shape");
+    if (fit_wx < 1 || fit_wy < 1 || search_wx < 0 || search_wy < 0 ||
+        ((search_wx == 0) != (search_wy == 0)))
+        return fail(SPX_E_ARG, "box dimensions must be positive (search box: both 0 = off)");
+    if ((int64_t)fit_wx * fit_wy > spx::kPeakMaxFitPoints)
+        return fail(SPX_E_SHAPE, "fit box larger than 1024 points");
+    if (nbatch == 0) return 0;
+    const unsigned grid = (unsigned)(nbatch < 65535 * 16 ? nbatch : 65535 * 16);
+    hipLaunchKernelGGL(spx::find_peak_kernel, dim3(grid), dim3(spx::kThreads), 0,
+                       reinterpret_cast<hipStream_t>(stream), image, mask, guess, nbatch, ny, nx,
+                       fit_wx, fit_wy, search_wx, search_wy, out_xy, out_status);
+    SPX_HIP(hipGetLastError());
+    return 0;
+}
+
+int spx_gather_cutouts_f32(const float* frame, const uint8_t* fmask, int fny, int fnx,
+                           const int32_t* boxes, int64_t nbatch, int tny, int tnx, float fill,
+                           float* tiles, void* stream) {
+    if (nbatch < 0 || (nbatch > 0 && (!frame || !boxes || !tiles)))
+        return fail(SPX_E_ARG, "null pointer or negative batch");
+    if (fny < 1 || fnx < 1 || tny < 1 || tnx < 1) return fail(SPX_E_SHAPE, "bad shape");
+    if (nbatch == 0) return 0;
+    const int64_t total = nbatch * tny * tnx;
+    const int64_t blocks = (total + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 65535 * 32 ? blocks : 65535 * 32);
+    hipLaunchKernelGGL(spx::gather_cutouts_kernel, dim3(grid), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), frame, fmask, fny, fnx, boxes, nbatch,
+                       tny, tnx, fill, tiles);
+    SPX_HIP(hipGetLastError());
+    return 0;
+}
+
+int spx_gen_gaussian_pairs_f32(uint64_t seed, int64_t first_index, int64_t nbatch, int n,
+                               float sigma_lo, float sigma_hi, float max_shift, float* ref,
+                               float* img, double* truth_dxdy, void* stream) {
+    if (nbatch < 0 || (nbatch > 0 && (!ref || !img)))
+        return fail(SPX_E_ARG, "null pointer or negative batch");
+    if (n < 1 || n > 4096) return fail(SPX_E_SHAPE, "bad tile size");
+    if (nbatch == 0) return 0;
+    const unsigned grid = (unsigned)(nbatch < 65535 * 16 ? nbatch : 65535 * 16);
+    hipLaunchKernelGGL(spx::gen_pairs_kernel, dim3(grid), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), seed, first_index, nbatch, n, sigma_lo,
+                       sigma_hi, max_shift, ref, img, truth_dxdy);
+    SPX_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,812 @@
+// spx_kernels.h -- CDNA4 (gfx950) kernels for subpixal's hot path:
+// per-cutout FFT cross-correlation + sub-pixel peak refinement.
+//
+// Replaces, for a whole batch at once, the body of the per-source loop at
+// /root/reference/subpixal/align.py:656-699, i.e.
+//   cc.find_displacement   (cc.py:21-95)   -> find_displacement5 kernel
+//   cc._build_icc_image    (cc.py:98-128)  -> cc_planes + icc interlace
+//   cc._normalize          (cc.py:131-156) -> stage_* (in-LDS statistics)
+//   centroid.find_peak     (centroid.py:18-236, hot-path arguments of cc.py:86)
+//                                          -> arg-max reduction + quad_fit
+// plus the pair / upsample=U mode of BASELINE.json.
+//
+// Design (DESIGN.md has the long form).  One 256-thread workgroup per cutout
+// pair, tile T = 64 (cutouts up to 64x64, zero padded), FFT period P = 2T = 128
+// as in scipy's fftconvolve (next_fast_len(2n-1)).  Zero padding makes the first
+// radix-2 DIF stage free:  Z[2k'+c] = FFT64{ z[x] w_P^(c x) }[k'],  so the
+// 128x128 spectrum splits into 4 parity classes (cy,cx), each a 64x64 complex
+// FFT.  Wave w owns class (w>>1, w&1) and keeps its 64x64 complex points in
+// registers as an 8x8 tile per lane; a 2-D FFT is two register rounds
+// (radix-8 in y and x) with ONE lane<->register transposition through LDS in
+// between.  ref and img are packed as z = ref + i*img; the cross-power spectrum
+// S = R conj(I) needs Z[k] and Z[-k], which live in the same class.  The inverse
+// runs the same rounds backwards and leaves, per class, the REAL plane
+//   d_c[l] = Re sum_{k in class c} S[k] e^{+2 pi i k l / P},   l in [0,64)^2,
+// in LDS.  The linear cross-correlation at lag l in [-32,31]^2 is
+//   cc[l] = P^-2 sum_c (-1)^(c . [l<0]) d_c[l mod 64]
+// and its trigonometric interpolant (the upsample=U mode) is
+//   F(t)  = P^-2 sum_c sum_m K_cy(ty-my) d_c[m] K_cx(tx-mx),
+// two small real matrix products per class, done with v_mfma_f32_16x16x4_f32.
+//
+// This header is compiled by hipcc for gfx950 (spx_capi.hip) and, unchanged, by
+// the CPU logic-check harness of the unit tests (tests/cpu_emu).  It needs the
+// names of spx_rt_hip.h (or the harness's equivalent) to be declared first.
+#pragma once
+
+namespace spx {
+
+using rt::f32x2;
+using rt::f32x4;
+typedef f32x2 cf;   // complex float: .x = re, .y = im
+
+constexpr int kThreads = 256;
+
+enum { ST_OK = 0, ST_EDGE = 1, ST_NOMAX = 2, ST_OUTSIDE = 3, ST_WINDOW = 4, ST_FEWPTS = 5 };
+enum { CC_PLAIN = 0, CC_NCC = 1, CC_ZNCC = 2 };
+
+// ---------------------------------------------------------------------------
+// complex helpers
+// ---------------------------------------------------------------------------
+SPX_DEVICE cf cmul(cf a, cf w) {
+    return cf{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x};
+}
+SPX_DEVICE cf cmulc(cf a, cf w) {   // a * conj(w)
+    return cf{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y};
+}
+template <int DIR> SPX_DEVICE cf ctw(cf a, cf w) {   // a * w (DIR>0) or a * conj(w)
+    return DIR > 0 ? cmul(a, w) : cmulc(a, w);
+}
+// multiply by -i (forward) / +i (inverse)
+template <int DIR> SPX_DEVICE cf mul_mi(cf a) {
+    return DIR > 0 ? cf{a.y, -a.x} : cf{-a.y, a.x};
+}
+// multiply by w8^1 = (1 - i)/sqrt2 (forward) / its conjugate
+template <int DIR> SPX_DEVICE cf mul_w8_1(cf a) {
+    const float h = 0.70710678118654752440f;
+    return DIR > 0 ? cf{(a.x + a.y) * h, (a.y - a.x) * h}
+                   : cf{(a.x - a.y) * h, (a.x + a.y) * h};
+}
+// multiply by w8^3 = (-1 - i)/sqrt2 (forward) / its conjugate
+template <int DIR> SPX_DEVICE cf mul_w8_3(cf a) {
+    const float h = 0.70710678118654752440f;
+    return DIR > 0 ? cf{(a.y - a.x) * h, -(a.x + a.y) * h}
+                   : cf{-(a.x + a.y) * h, (a.x - a.y) * h};
+}
+
+// 4-point DFT, natural order in and out
+template <int DIR>
+SPX_DEVICE void fft4(cf c0, cf c1, cf c2, cf c3, cf& y0, cf& y1, cf& y2, cf& y3) {
+    cf s0 = c0 + c2, s1 = c0 - c2, s2 = c1 + c3, s3 = mul_mi<DIR>(c1 - c3);
+    y0 = s0 + s2;
+    y2 = s0 - s2;
+    y1 = s1 + s3;
+    y3 = s1 - s3;
+}
+
+// 8-point DFT, natural order in and out (radix-2 DIF + two radix-4):
+// X[k] = sum_j a[j] e^{-DIR 2 pi i j k / 8}
+template <int DIR> SPX_DEVICE void fft8(cf (&a)[8]) {
+    cf b0 = a[0] + a[4], b4 = a[0] - a[4];
+    cf b1 = a[1] + a[5], b5 = mul_w8_1<DIR>(a[1] - a[5]);
+    cf b2 = a[2] + a[6], b6 = mul_mi<DIR>(a[2] - a[6]);
+    cf b3 = a[3] + a[7], b7 = mul_w8_3<DIR>(a[3] - a[7]);
+    fft4<DIR>(b0, b1, b2, b3, a[0], a[2], a[4], a[6]);
+    fft4<DIR>(b4, b5, b6, b7, a[1], a[3], a[5], a[7]);
+}
+
+// radix-8 along the first (y) digit of an 8x8 register tile
+template <int DIR> SPX_DEVICE void fft8_y(cf (&v)[8][8]) {
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        cf t[8];
+#pragma unroll
+        for (int y = 0; y < 8; ++y) t[y] = v[y][x];
+        fft8<DIR>(t);
+#pragma unroll
+        for (int y = 0; y < 8; ++y) v[y][x] = t[y];
+    }
+}
+// radix-8 along the second (x) digit
+template <int DIR> SPX_DEVICE void fft8_x(cf (&v)[8][8]) {
+#pragma unroll
+    for (int y = 0; y < 8; ++y) fft8<DIR>(v[y]);
+}
+
+// ---------------------------------------------------------------------------
+// LDS map (bytes).  Everything is carved from one dynamic region.
+// ---------------------------------------------------------------------------
+template <int C> struct Lds {
+    static constexpr int P = 64 * C;          // FFT period
+    static constexpr int T = 32 * C;          // tile (max cutout side)
+    static constexpr int NCLS = C * C;        // parity classes = waves
+    static constexpr int ZS = 72;             // staged-input row stride (floats)
+    static constexpr int XS = 68;             // transposition row stride (floats)
+    static constexpr int PS = 64;             // class-plane row stride (floats)
+    static constexpr int TW_OFF = 0;                      // cf[P]
+    static constexpr int SCR_OFF = TW_OFF + P * 8;        // 1 KiB scratch
+    static constexpr int R_OFF = SCR_OFF + 1024;          // phase-shared region
+    static constexpr int ZBUF_BYTES = 2 * 64 * ZS * 4;
+    static constexpr int XCH_WAVE_BYTES = 64 * XS * 4;
+    static constexpr int XCH_BYTES = NCLS * XCH_WAVE_BYTES;
+    static constexpr int PLANE_BYTES = 64 * PS * 4;
+    static constexpr int PLANES_BYTES = NCLS * PLANE_BYTES;
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    // fine window of W x W floats sits behind the planes
+    static constexpr int total(int W) {
+        return R_OFF + cmax(cmax(ZBUF_BYTES, XCH_BYTES), PLANES_BYTES + W * W * 4);
+    }
+};
+
+// scratch (1 KiB) sub-offsets
+constexpr int SCR_RED_F = 0;      // float[4]  per-wave reduction values
+constexpr int SCR_RED_I = 16;     // int[4]    per-wave reduction indices
+constexpr int SCR_INT = 64;       // int[16]   broadcast integers
+constexpr int SCR_RED_D = 128;    // double[4*4] per-wave double partials
+constexpr int SCR_FIT = 256;      // double[25] fit box values
+constexpr int SCR_STAT = 512;     // double[8]  statistics
+
+// ---------------------------------------------------------------------------
+// workgroup reductions
+// ---------------------------------------------------------------------------
+SPX_DEVICE double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += rt::shfl_xor(v, m);
+    return v;
+}
+
+// sums NV doubles over the workgroup (fixed order: lanes by butterfly, waves
+// 0..3); every thread gets the totals.  Two barriers.
+template <int NV> SPX_DEVICE void block_sum(unsigned char* lds_scr, double (&v)[NV]) {
+    const int tid = rt::thread_id();
+    double* part = reinterpret_cast<double*>(lds_scr + SCR_RED_D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) part[(tid >> 6) * 4 + i] = v[i];
+    }
+    rt::block_sync();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double s = 0.0;
+        for (int w = 0; w < kThreads / 64; ++w) s += part[w * 4 + i];
+        v[i] = s;
+    }
+    rt::block_sync();
+}
+
+// (value, index) arg-max with centroid.py:114's tie rule: the FIRST maximum in
+// row-major order, i.e. larger value wins, equal values -> smaller index.
+SPX_DEVICE bool better(float v, int i, float bv, int bi) {
+    return (v > bv) || (v == bv && i < bi);
+}
+SPX_DEVICE void block_argmax(unsigned char* lds_scr, float& v, int& idx) {
+    const int tid = rt::thread_id();
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        float ov = rt::shfl_xor(v, m);
+        int oi = rt::shfl_xor(idx, m);
+        if (better(ov, oi, v, idx)) { v = ov; idx = oi; }
+    }
+    float* rf = reinterpret_cast<float*>(lds_scr + SCR_RED_F);
+    int* ri = reinterpret_cast<int*>(lds_scr + SCR_RED_I);
+    if ((tid & 63) == 0) { rf[tid >> 6] = v; ri[tid >> 6] = idx; }
+    rt::block_sync();
+    v = rf[0];
+    idx = ri[0];
+    for (int w = 1; w < kThreads / 64; ++w)
+        if (better(rf[w], ri[w], v, idx)) { v = rf[w]; idx = ri[w]; }
+    rt::block_sync();
+}
+
+// ---------------------------------------------------------------------------
+// 5x5 quadratic least squares as a constant operator:
+// c = pinv(V) d on box-relative, centred coordinates (-2..2)^2, float64.
+// Rows: 1, x, y, xy, x^2, y^2.  Replaces numpy.linalg.lstsq at centroid.py:207.
+// For the centred 5x5 grid the normal equations decouple:
+//   c10 = sum(x d)/50, c01 = sum(y d)/50, c11 = sum(xy d)/100,
+//   c20 = (sum(x^2 d) - 2 sum(d))/70, c02 = (sum(y^2 d) - 2 sum(d))/70.
+// ---------------------------------------------------------------------------
+struct PeakResult {
+    double x, y;
+    int status;
+};
+
+// d: 25 values, row-major (y outer), of the box whose first pixel is (x1, y1);
+// (imax, jmax): integer arg-max; (nx, ny): image size (centroid.py:217-236).
+SPX_DEVICE PeakResult quad_fit_5x5(const double* d, int x1, int y1, int imax, int jmax,
+                                   int nx, int ny) {
+    double s0 = 0, sx = 0, sy = 0, sxy = 0, sxx = 0, syy = 0;
+    for (int j = 0; j < 5; ++j) {
+        for (int i = 0; i < 5; ++i) {
+            double v = d[j * 5 + i];
+            double x = (double)(i - 2), y = (double)(j - 2);
+            s0 += v;
+            sx += x * v;
+            sy += y * v;
+            sxy += x * y * v;
+            sxx += x * x * v;
+            syy += y * y * v;
+        }
+    }
+    const double c10 = sx / 50.0, c01 = sy / 50.0, c11 = sxy / 100.0;
+    const double c20 = (sxx - 2.0 * s0) / 70.0, c02 = (syy - 2.0 * s0) / 70.0;
+    PeakResult r;
+    const double det = 4.0 * c02 * c20 - c11 * c11;
+    if (det <= 0.0 || ((c20 > 0.0 && c02 >= 0.0) || (c20 >= 0.0 && c02 > 0.0))) {
+        r.x = x1 + 2.5;           // (x1 + x2)/2 with x2 exclusive: centroid.py:225
+        r.y = y1 + 2.5;
+        r.status = ST_NOMAX;
+        return r;
+    }
+    const double xm = (x1 + 2) + (c01 * c11 - 2.0 * c02 * c10) / det;
+    const double ym = (y1 + 2) + (c10 * c11 - 2.0 * c01 * c20) / det;
+    if (xm > 0.0 && xm < nx - 1.0 && ym > 0.0 && ym < ny - 1.0) {
+        r.x = xm;
+        r.y = ym;
+        r.status = ST_OK;
+    } else {
+        r.x = (double)imax;       // centroid.py:230-236 (auto_expand_search False)
+        r.y = (double)jmax;
+        r.status = ST_OUTSIDE;
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// Stage one (ref, img) pair into the LDS input planes, zero padded to 64x64,
+// with cc.py:131-156's normalisation (pool = this one image, or the `npool`
+// images of the 5-image mode whose statistics the caller passes in).
+// ---------------------------------------------------------------------------
+struct NormStats {      // what _normalize applies: im = (im - mean)/std on im != 0
+    float im_mean, im_std, ref_mean, ref_std;
+    int active;         // 0: plain CC
+};
+
+template <int C>
+SPX_DEVICE void stage_pair(unsigned char* lds, const float* __restrict__ ref,
+                           const float* __restrict__ img, int ny, int nx,
+                           const NormStats& ns) {
+    typedef Lds<C> L;
+    const int tid = rt::thread_id();
+    float* zre = reinterpret_cast<float*>(lds + L::R_OFF);
+    float* zim = zre + 64 * L::ZS;
+    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
+        const int y = idx >> 6, x = idx & 63;
+        float r = 0.0f, m = 0.0f;
+        if (y < ny && x < nx) {
+            r = ref[(int64_t)y * nx + x];
+            m = img[(int64_t)y * nx + x];
+            if (ns.active) {
+                if (m != 0.0f) {           // cc.py:144-148: masked pixels only
+                    m = m - ns.im_mean;
+                    m = m / ns.im_std;
+                }
+                r = r - ns.ref_mean;       // cc.py:153-154: all pixels
+                r = r / ns.ref_std;
+            }
+        }
+        zre[y * L::ZS + x] = r;
+        zim[y * L::ZS + x] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// cc_planes: staged input planes -> the NCLS real class planes d_c in LDS.
+// Caller must have issued a block_sync after staging; ends with a block_sync.
+// ---------------------------------------------------------------------------
+template <int C> SPX_DEVICE void cc_planes(unsigned char* lds) {
+    typedef Lds<C> L;
+    static_assert(C == 2, "class decomposition implemented for P = 128");
+    const int tid = rt::thread_id();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int cy = wave / C, cx = wave % C;       // this wave's parity class
+    const int l1 = lane >> 3, l0 = lane & 7;      // lane digits (y-ish, x-ish)
+    const cf* tw = reinterpret_cast<const cf*>(lds + L::TW_OFF);
+    const float* zre = reinterpret_cast<const float*>(lds + L::R_OFF);
+    const float* zim = zre + 64 * L::ZS;
+    float* xch = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::XCH_WAVE_BYTES);
+
+    cf v[8][8];
+
+    // ---- forward round A: lane = (y0, x0), registers = (y1, x1); y = y0 + 8 y1
+#pragma unroll
+    for (int y1 = 0; y1 < 8; ++y1)
+#pragma unroll
+        for (int x1 = 0; x1 < 8; ++x1) {
+            const int a = (l1 + 8 * y1) * L::ZS + l0 + 8 * x1;
+            v[y1][x1] = cf{zre[a], zim[a]};
+        }
+    rt::block_sync();                       // all waves have read the staged input
+
+    // class pre-twiddle w_P^{c (8 y1)} (the free radix-2 stage of the zero pad)
+    if (cy) {
+#pragma unroll
+        for (int y1 = 1; y1 < 8; ++y1) {
+            const cf w = tw[8 * cy * y1];
+#pragma unroll
+            for (int x1 = 0; x1 < 8; ++x1) v[y1][x1] = cmul(v[y1][x1], w);
+        }
+    }
+    if (cx) {
+#pragma unroll
+        for (int x1 = 1; x1 < 8; ++x1) {
+            const cf w = tw[8 * cx * x1];
+#pragma unroll
+            for (int y1 = 0; y1 < 8; ++y1) v[y1][x1] = cmul(v[y1][x1], w);
+        }
+    }
+    fft8_y<1>(v);                           // y1 -> kyb
+    fft8_x<1>(v);                           // x1 -> kxb
+    // twiddle w_P^{y0 (cy + C kyb)} w_P^{x0 (cx + C kxb)}
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const cf wy = tw[l1 * (cy + C * kb)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[kb][j] = cmul(v[kb][j], wy);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const cf wx = tw[l0 * (cx + C * kb)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j][kb] = cmul(v[j][kb], wx);
+    }
+
+    // ---- transposition: (lane (y0,x0), reg (kyb,kxb)) -> (lane (kyb,kxb), reg (y0,x0))
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int r = 0; r < 64; ++r)
+            xch[r * L::XS + lane] = part ? v[r >> 3][r & 7].y : v[r >> 3][r & 7].x;
+        rt::wave_sync();
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            const float t = xch[lane * L::XS + r];
+            if (part) v[r >> 3][r & 7].y = t; else v[r >> 3][r & 7].x = t;
+        }
+        rt::wave_sync();
+    }
+
+    // ---- forward round B: lane = (kyb, kxb), registers (y0, x0) -> (kya, kxa)
+    fft8_y<1>(v);
+    fft8_x<1>(v);
+    // now v[kya][kxa] = Z[ky][kx], ky = cy + C*l1 + 8C*kya, kx = cx + C*l0 + 8C*kxa
+
+    // ---- cross-power spectrum S = R conj(I) from Z[k] and Z[-k] (same class)
+    //   Re S = Im(Z[k] Z[-k]) / 2,   Im S = (|Z[k]|^2 - |Z[-k]|^2) / 4
+    {
+        // partner lane / register digits for -k (mod P)
+        const int zy = (cy == 0 && l1 == 0), zx = (cx == 0 && l0 == 0);
+        const int pl1 = cy ? 7 - l1 : (8 - l1) & 7;
+        const int pl0 = cx ? 7 - l0 : (8 - l0) & 7;
+        const int plane_ = pl1 * 8 + pl0;
+        // Two phases through the 16 KiB buffer: partner real parts are parked in
+        // registers, partner imaginary parts are consumed as they arrive.
+        float znre[8][8];
+#pragma unroll
+        for (int r = 0; r < 64; ++r) xch[r * L::XS + lane] = v[r >> 3][r & 7].x;
+        rt::wave_sync();
+#pragma unroll
+        for (int ka = 0; ka < 8; ++ka) {
+            const int pka = (7 - ka + zy) & 7;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const int pkb = (7 - kb + zx) & 7;
+                znre[ka][kb] = xch[(pka * 8 + pkb) * L::XS + plane_];
+            }
+        }
+        rt::wave_sync();
+#pragma unroll
+        for (int r = 0; r < 64; ++r) xch[r * L::XS + lane] = v[r >> 3][r & 7].y;
+        rt::wave_sync();
+#pragma unroll
+        for (int ka = 0; ka < 8; ++ka) {
+            const int pka = (7 - ka + zy) & 7;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const int pkb = (7 - kb + zx) & 7;
+                const cf a = v[ka][kb];
+                const cf b = cf{znre[ka][kb], xch[(pka * 8 + pkb) * L::XS + plane_]};
+                v[ka][kb] = cf{0.5f * (a.x * b.y + a.y * b.x),
+                               0.25f * ((a.x * a.x + a.y * a.y) - (b.x * b.x + b.y * b.y))};
+            }
+        }
+        rt::wave_sync();
+    }
+
+    // ---- inverse round A': registers (kya, kxa) -> (y0, x0), lane = (kyb, kxb)
+    fft8_y<-1>(v);
+    fft8_x<-1>(v);
+#pragma unroll
+    for (int y0 = 0; y0 < 8; ++y0) {
+        const cf wy = tw[y0 * (cy + C * l1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[y0][j] = cmulc(v[y0][j], wy);
+    }
+#pragma unroll
+    for (int x0 = 0; x0 < 8; ++x0) {
+        const cf wx = tw[x0 * (cx + C * l0)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j][x0] = cmulc(v[j][x0], wx);
+    }
+    // ---- transposition back: -> lane (y0, x0), registers (kyb, kxb)
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int r = 0; r < 64; ++r)
+            xch[r * L::XS + lane] = part ? v[r >> 3][r & 7].y : v[r >> 3][r & 7].x;
+        rt::wave_sync();
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            const float t = xch[lane * L::XS + r];
+            if (part) v[r >> 3][r & 7].y = t; else v[r >> 3][r & 7].x = t;
+        }
+        rt::wave_sync();
+    }
+    // ---- inverse round B': registers (kyb, kxb) -> (y1, x1)
+    fft8_y<-1>(v);
+    fft8_x<-1>(v);
+    // class post-twiddle conj(w_P^{8 (cy y1 + cx x1)}); only the real part is kept
+    rt::block_sync();      // every wave is done with its transposition buffer
+    float* plane = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::PLANE_BYTES);
+#pragma unroll
+    for (int y1 = 0; y1 < 8; ++y1) {
+        const cf wy = tw[8 * cy * y1];
+#pragma unroll
+        for (int x1 = 0; x1 < 8; ++x1) {
+            const cf wx = tw[8 * cx * x1];
+            const cf w = cmul(wy, wx);
+            const cf a = v[y1][x1];
+            plane[(l1 + 8 * y1) * L::PS + l0 + 8 * x1] = a.x * w.x + a.y * w.y;  // Re(a conj w)
+        }
+    }
+    rt::block_sync();
+}
+
+// cross-correlation value at flipped 'same'-window index (qy, qx) of a
+// (ny, nx) cutout: lag l = (n - 1 - q) - n/2  (cc.py:114-126 flips the window).
+template <int C>
+SPX_DEVICE float window_value(const unsigned char* lds, int ny, int nx, int qy, int qx) {
+    typedef Lds<C> L;
+    const float* planes = reinterpret_cast<const float*>(lds + L::R_OFF);
+    const int ly = (ny - 1 - qy) - ny / 2, lx = (nx - 1 - qx) - nx / 2;
+    const int my = ly & 63, mx = lx & 63;
+    const int sy = ly < 0, sx = lx < 0;
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C * C; ++c) {
+        const float d = planes[c * (64 * L::PS) + my * L::PS + mx];
+        const int neg = ((c / C) & sy) ^ ((c % C) & sx);
+        acc += neg ? -d : d;
+    }
+    return acc * (1.0f / (float)(L::P * L::P));
+}
+
+// ---------------------------------------------------------------------------
+// statistics for cc.py:131-156 over `npool` images (1: pair mode, 4: 5-image)
+// ---------------------------------------------------------------------------
+SPX_DEVICE NormStats norm_stats(unsigned char* lds_scr, const float* __restrict__ ref,
+                                const float* __restrict__ ims, int npool, int64_t im_stride,
+                                int ny, int nx, int cc_type) {
+    NormStats ns;
+    ns.active = 0;
+    ns.im_mean = 0.0f; ns.im_std = 1.0f; ns.ref_mean = 0.0f; ns.ref_std = 1.0f;
+    if (cc_type == CC_PLAIN) return ns;
+    const int tid = rt::thread_id();
+    const int npx = ny * nx;
+    // pass 1: counts and sums (pooled image pixels != 0; ref over the union mask)
+    double a[4] = {0.0, 0.0, 0.0, 0.0};   // n_im, sum_im, n_union, sum_ref
+    for (int i = tid; i < npx; i += kThreads) {
+        bool any = false;
+        for (int q = 0; q < npool; ++q) {
+            const float m = ims[q * im_stride + i];
+            if (m != 0.0f) { a[0] += 1.0; a[1] += (double)m; any = true; }
+        }
+        if (any) { a[2] += 1.0; a[3] += (double)ref[i]; }
+    }
+    block_sum<4>(lds_scr, a);
+    const double im_mean = a[1] / a[0], ref_mean = a[3] / a[2];
+    const double n_im = a[0], n_un = a[2];
+    // pass 2: population variances about the true means (numpy std, ddof = 0)
+    double b[2] = {0.0, 0.0};
+    for (int i = tid; i < npx; i += kThreads) {
+        bool any = false;
+        for (int q = 0; q < npool; ++q) {
+            const float m = ims[q * im_stride + i];
+            if (m != 0.0f) { const double d = (double)m - im_mean; b[0] += d * d; any = true; }
+        }
+        if (any) { const double d = (double)ref[i] - ref_mean; b[1] += d * d; }
+    }
+    block_sum<2>(lds_scr, b);
+    ns.active = 1;
+    const bool zero = (cc_type == CC_ZNCC);
+    ns.im_mean = zero ? (float)im_mean : 0.0f;
+    ns.im_std = (float)sqrt(b[0] / n_im);
+    ns.ref_mean = zero ? (float)ref_mean : 0.0f;
+    ns.ref_std = (float)sqrt(b[1] / n_un);
+    return ns;
+}
+
+// ---------------------------------------------------------------------------
+// peak of a virtual NX x NY image given its arg-max and an accessor for values:
+// centroid.py:158-236 for peak_fit_box=5 on images >= 5x5.  Thread 0 returns the
+// result; `val(x, y)` is evaluated by threads 0..24.
+// ---------------------------------------------------------------------------
+template <typename ValFn>
+SPX_DEVICE PeakResult peak_from_argmax(unsigned char* lds_scr, int imax, int jmax,
+                                       int NX, int NY, ValFn val) {
+    const int tid = rt::thread_id();
+    PeakResult r;
+    r.x = (double)imax; r.y = (double)jmax; r.status = ST_EDGE;
+    if (imax == 0 || jmax == 0) return r;              // centroid.py:171-172
+    int x1 = imax - 2, y1 = jmax - 2;                  // centroid.py:165-184
+    if (x1 > NX - 5) x1 = NX - 5;
+    if (y1 > NY - 5) y1 = NY - 5;
+    if (x1 < 0) x1 = 0;
+    if (y1 < 0) y1 = 0;
+    double* fit = reinterpret_cast<double*>(lds_scr + SCR_FIT);
+    if (tid < 25) fit[tid] = (double)val(x1 + tid % 5, y1 + tid / 5);
+    rt::block_sync();
+    if (tid == 0) r = quad_fit_5x5(fit, x1, y1, imax, jmax, NX, NY);
+    rt::block_sync();
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// Fine (upsampled) window by MFMA.  ktab: float [2][W][64],
+//   ktab[c][a][m] = K_c( -(a - W/2)/U - (m - 32) ),
+//   K_0(t) = 1/64 [1 + 2 sum_{j=1..31} cos(2 pi 2j t / P) + cos(2 pi 64 t / P)],
+//   K_1(t) = 2/64 sum_{j odd, 1..63} cos(2 pi j t / P)                (P = 128).
+// Computes, for fine offsets a', b' in [-W/2, W/2) around flipped coarse index
+// (qyc, qxc):  F[b][a] = cc interpolated at q = U*qc + offset, into fbuf[b*W+a]
+// (note the transposed storage: first index is the x offset).
+// ---------------------------------------------------------------------------
+template <int C, int WB>
+SPX_DEVICE void fine_window(unsigned char* lds, const float* __restrict__ ktab,
+                            int ny, int nx, int qyc, int qxc) {
+    typedef Lds<C> L;
+    static_assert(C == 2, "");
+    constexpr int W = 16 * WB;
+    const int tid = rt::thread_id();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int cy = wave / C, cx = wave % C;
+    const int lk = lane >> 4, lj = lane & 15;
+    const float* plane = reinterpret_cast<const float*>(lds + L::R_OFF + wave * L::PLANE_BYTES);
+    float* fbuf = reinterpret_cast<float*>(lds + L::R_OFF + L::PLANES_BYTES);
+    // integer lags of the window centre
+    const int lyc = (ny - 1 - qyc) - ny / 2, lxc = (nx - 1 - qxc) - nx / 2;
+    const float* ky = ktab + (size_t)cy * W * 64;
+    const float* kx = ktab + (size_t)cx * W * 64;
+
+    // stage 1: G^T[mx][a] = sum_m'' plane[(lyc + m'') & 63][mx] * sgn * ky[a][m''+32]
+    f32x4 acc[WB][4];
+#pragma unroll
+    for (int ab = 0; ab < WB; ++ab)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[ab][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int step = 0; step < 16; ++step) {
+        const int mi = 4 * step + lk;              // table index m''+32
+        const int m = lyc + mi - 32;               // lag of that plane row
+        const int row = m & 63;
+        // d_c[m] = (-1)^(cy * floor(m/64)) plane[m mod 64]
+        const float sgn = (cy && ((m >> 6) & 1)) ? -1.0f : 1.0f;
+        float bfrag[WB];
+#pragma unroll
+        for (int ab = 0; ab < WB; ++ab) bfrag[ab] = sgn * ky[(ab * 16 + lj) * 64 + mi];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float afrag = plane[row * L::PS + t * 16 + lj];
+#pragma unroll
+            for (int ab = 0; ab < WB; ++ab)
+                acc[ab][t] = rt::mfma_16x16x4(afrag, bfrag[ab], acc[ab][t]);
+        }
+    }
+    // stage 2: F^T[b][a] = sum_mx kxs[b][mx] G^T[mx][a]; the accumulator register r
+    // of tile t is the B operand row k' = lane>>4 for mx = 16 t + 4 k' + r.
+    f32x4 f[WB][WB];
+#pragma unroll
+    for (int bb = 0; bb < WB; ++bb)
+#pragma unroll
+        for (int ab = 0; ab < WB; ++ab) f[bb][ab] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mx = 16 * t + 4 * lk + r;             // raw plane column
+            const int mrel = ((mx - lxc + 32) & 63) - 32;   // m'' in [-32, 31]
+            const int m = lxc + mrel;                        // actual lag
+            const float sgn = (cx && ((m >> 6) & 1)) ? -1.0f : 1.0f;
+#pragma unroll
+            for (int bb = 0; bb < WB; ++bb) {
+                const float afrag = sgn * kx[(bb * 16 + lj) * 64 + mrel + 32];
+#pragma unroll
+                for (int ab = 0; ab < WB; ++ab)
+                    f[bb][ab] = rt::mfma_16x16x4(afrag, acc[ab][t][r], f[bb][ab]);
+            }
+        }
+    // sum the 4 classes in fixed order through LDS
+    const float scale = 1.0f / (float)(L::P * L::P);
+    for (int c = 0; c < C * C; ++c) {
+        if (wave == c) {
+#pragma unroll
+            for (int bb = 0; bb < WB; ++bb)
+#pragma unroll
+                for (int ab = 0; ab < WB; ++ab)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int b = bb * 16 + 4 * lk + r, a = ab * 16 + lj;
+                        const float val = f[bb][ab][r] * scale;
+                        if (c == 0) fbuf[b * W + a] = val; else fbuf[b * W + a] += val;
+                    }
+        }
+        rt::block_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Pair kernel: one workgroup per (ref, img) pair.
+//   out[2*pair + {0,1}] = (dx, dy) float64, status[pair]
+// ---------------------------------------------------------------------------
+template <int C, int WB>
+SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict__ img,
+                          int ny, int nx, int U, int cc_type, const cf* __restrict__ tw_g,
+                          const float* __restrict__ ktab, double* __restrict__ out,
+                          int* __restrict__ status, unsigned char* lds) {
+    typedef Lds<C> L;
+    const int tid = rt::thread_id();
+    unsigned char* scr = lds + L::SCR_OFF;
+    cf* tw = reinterpret_cast<cf*>(lds + L::TW_OFF);
+    for (int i = tid; i < L::P; i += kThreads) tw[i] = tw_g[i];
+
+    const NormStats ns = norm_stats(scr, ref, img, 1, 0, ny, nx, cc_type);
+    stage_pair<C>(lds, ref, img, ny, nx, ns);
+    rt::block_sync();
+    cc_planes<C>(lds);
+
+    // coarse arg-max over the flipped 'same' window (centroid.py:114-116)
+    float bv = -__builtin_inff();
+    int bi = 0x7fffffff;
+    for (int idx = tid; idx < ny * nx; idx += kThreads) {
+        const float val = window_value<C>(lds, ny, nx, idx / nx, idx % nx);
+        if (better(val, idx, bv, bi)) { bv = val; bi = idx; }
+    }
+    block_argmax(scr, bv, bi);
+    int qyc = bi / nx, qxc = bi % nx;
+
+    PeakResult pk;
+    if constexpr (WB == 0) {
+        pk = peak_from_argmax(scr, qxc, qyc, nx, ny, [&](int x, int y) {
+            return window_value<C>(lds, ny, nx, y, x);
+        });
+    } else {
+        constexpr int W = 16 * (WB > 0 ? WB : 1);
+        const int NX = U * nx, NY = U * ny;
+        const float* fbuf = reinterpret_cast<const float*>(lds + L::R_OFF + L::PLANES_BYTES);
+        int imax = 0, jmax = 0;
+        bool inside = false;
+        for (int iter = 0; iter < 4; ++iter) {
+            fine_window<C, (WB > 0 ? WB : 1)>(lds, ktab, ny, nx, qyc, qxc);
+            // arg-max over the part of the window inside the virtual image
+            const int fx0 = U * qxc - W / 2, fy0 = U * qyc - W / 2;
+            float fv = -__builtin_inff();
+            int fi = 0x7fffffff;
+            for (int idx = tid; idx < W * W; idx += kThreads) {
+                const int a = idx / W, b = idx % W;       // a: y offset, b: x offset
+                const int gy = fy0 + a, gx = fx0 + b;
+                if (gy >= 0 && gy < NY && gx >= 0 && gx < NX) {
+                    const float val = fbuf[b * W + a];
+                    if (better(val, idx, fv, fi)) { fv = val; fi = idx; }
+                }
+            }
+            block_argmax(scr, fv, fi);
+            const int a = fi / W, b = fi % W;
+            jmax = fy0 + a;
+            imax = fx0 + b;
+            // the 5x5 box (clamped into the image) must lie inside the window
+            int x1 = imax - 2, y1 = jmax - 2;
+            if (x1 > NX - 5) x1 = NX - 5;
+            if (y1 > NY - 5) y1 = NY - 5;
+            if (x1 < 0) x1 = 0;
+            if (y1 < 0) y1 = 0;
+            const bool okx = (x1 >= fx0 && x1 + 4 < fx0 + W) || imax == 0;
+            const bool oky = (y1 >= fy0 && y1 + 4 < fy0 + W) || jmax == 0;
+            if (okx && oky) { inside = true; break; }
+            // move the window centre one coarse pixel towards the peak and redo
+            if (!okx) qxc += (b < W / 2) ? -1 : 1;
+            if (!oky) qyc += (a < W / 2) ? -1 : 1;
+            qxc = qxc < 0 ? 0 : (qxc > nx - 1 ? nx - 1 : qxc);
+            qyc = qyc < 0 ? 0 : (qyc > ny - 1 ? ny - 1 : qyc);
+        }
+        if (inside) {
+            const int fx0 = U * qxc - W / 2, fy0 = U * qyc - W / 2;
+            pk = peak_from_argmax(scr, imax, jmax, NX, NY, [&](int x, int y) {
+                return fbuf[(x - fx0) * W + (y - fy0)];
+            });
+        } else {
+            pk.x = (double)imax; pk.y = (double)jmax; pk.status = ST_WINDOW;
+        }
+    }
+    if (tid == 0) {
+        // cc.py:89-93 with the interlace factor 2 replaced by U
+        out[0] = pk.x / (double)U - (double)((nx - 1) / 2);
+        out[1] = pk.y / (double)U - (double)((ny - 1) / 2);
+        if (status) status[0] = pk.status;
+    }
+}
+
+template <int C, int WB>
+SPX_TKERNEL(256) void pair_kernel(const float* __restrict__ ref, const float* __restrict__ img,
+                                  int64_t nbatch, int ny, int nx, int U, int cc_type,
+                                  const cf* __restrict__ tw_g, const float* __restrict__ ktab,
+                                  double* __restrict__ out, int* __restrict__ status) {
+    SPX_DYN_LDS(lds);
+    const int64_t stride = (int64_t)ny * nx;
+    for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
+        pair_body<C, WB>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, tw_g, ktab,
+                         out + 2 * p, status ? status + p : nullptr, lds);
+        rt::block_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 5-image reference mode (cc.find_displacement, cc.py:21-95): ref against the 4
+// half-pixel dithers, interlaced 2x image, arg-max, 5x5 fit on the 2x grid.
+// icc: float [2ny][2nx] per item in global memory (user output or workspace).
+// ---------------------------------------------------------------------------
+template <int C>
+SPX_DEVICE void disp5_body(const float* __restrict__ ref, const float* __restrict__ im4,
+                           int ny, int nx, int cc_type, const cf* __restrict__ tw_g,
+                           float* __restrict__ icc, double* __restrict__ out,
+                           int* __restrict__ status, unsigned char* lds) {
+    typedef Lds<C> L;
+    const int tid = rt::thread_id();
+    unsigned char* scr = lds + L::SCR_OFF;
+    cf* tw = reinterpret_cast<cf*>(lds + L::TW_OFF);
+    for (int i = tid; i < L::P; i += kThreads) tw[i] = tw_g[i];
+    const int64_t stride = (int64_t)ny * nx;
+    const NormStats ns = norm_stats(scr, ref, im4, 4, stride, ny, nx, cc_type);
+
+    float bv = -__builtin_inff();
+    int bi = 0x7fffffff;
+    const int NX = 2 * nx, NY = 2 * ny;
+    for (int q = 0; q < 4; ++q) {            // order 00, 10, 01, 11 (cc.py:114-117)
+        const int ox = q & 1, oy = q >> 1;   // icc[oy::2, ox::2] = cc[::-1, ::-1]
+        stage_pair<C>(lds, ref, im4 + q * stride, ny, nx, ns);
+        rt::block_sync();
+        cc_planes<C>(lds);
+        for (int idx = tid; idx < ny * nx; idx += kThreads) {
+            const int qy = idx / nx, qx = idx % nx;
+            const float val = window_value<C>(lds, ny, nx, qy, qx);
+            const int gi = (2 * qy + oy) * NX + 2 * qx + ox;
+            icc[gi] = val;
+            if (better(val, gi, bv, bi)) { bv = val; bi = gi; }
+        }
+        rt::block_sync();                    // planes are overwritten by the next stage
+    }
+    block_argmax(scr, bv, bi);
+    const int jmax = bi / NX, imax = bi % NX;
+    PeakResult pk = peak_from_argmax(scr, imax, jmax, NX, NY, [&](int x, int y) {
+        return icc[y * NX + x];
+    });
+    if (tid == 0) {
+        out[0] = 0.5 * pk.x - (double)((NX - 1) / 4);     // cc.py:89-93
+        out[1] = 0.5 * pk.y - (double)((NY - 1) / 4);
+        if (status) status[0] = pk.status;
+    }
+}
+
+template <int C>
+SPX_TKERNEL(256) void disp5_kernel(const float* __restrict__ ref, const float* __restrict__ im4,
+                                   int64_t nbatch, int ny, int nx, int cc_type,
+                                   const cf* __restrict__ tw_g, float* __restrict__ icc,
+                                   double* __restrict__ out, int* __restrict__ status) {
+    SPX_DYN_LDS(lds);
+    const int64_t stride = (int64_t)ny * nx;
+    for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
+        disp5_body<C>(ref + p * stride, im4 + 4 * p * stride, ny, nx, cc_type, tw_g,
+                      icc + 4 * p * stride, out + 2 * p, status ? status + p : nullptr, lds);
+        rt::block_sync();
+    }
+}
+
+}  // namespace spx

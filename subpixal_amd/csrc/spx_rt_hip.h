@@ -1,0 +1,48 @@
+// Device-side runtime layer for the kernels in spx_kernels.h: gfx950 only.
+// (tests/cpu_emu/spx_rt_emu.h provides the same names for the CPU logic-check
+// build used by the unit tests; the product library is built from this file.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spx {
+namespace rt {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SPX_DEVICE __device__ __forceinline__
+#define SPX_KERNEL(nthreads) extern "C" __global__ __launch_bounds__(nthreads)
+#define SPX_TKERNEL(nthreads) __global__ __launch_bounds__(nthreads)
+// all LDS lives in ONE dynamic region (cdna guide G17: keep the base 16-B aligned)
+#define SPX_STATIC_LDS(type, name, count) __shared__ type name[count]
+#define SPX_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+
+SPX_DEVICE int thread_id() { return (int)threadIdx.x; }
+SPX_DEVICE int64_t block_id() { return (int64_t)blockIdx.x; }
+SPX_DEVICE int64_t grid_size() { return (int64_t)gridDim.x; }
+
+// workgroup barrier (LDS + global visibility at workgroup scope)
+SPX_DEVICE void block_sync() { __syncthreads(); }
+
+// Ordering point between LDS accesses of the lanes of ONE wave (per-wave LDS
+// regions).  A wave's DS instructions execute in issue order, so only the
+// compiler has to be stopped from reordering across this point.
+SPX_DEVICE void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+SPX_DEVICE float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+SPX_DEVICE int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
+SPX_DEVICE double shfl_xor(double v, int m) { return __shfl_xor(v, m, 64); }
+
+// v_mfma_f32_16x16x4_f32: lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15];
+// D[row=4*(l>>4)+r][col=l&15] in register r.  Exact f32 fma chain over k.
+SPX_DEVICE f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+}  // namespace rt
+}  // namespace spx

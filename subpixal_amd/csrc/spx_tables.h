@@ -1,0 +1,62 @@
+// Host-side constant tables for the kernels in spx_kernels.h (plain C++).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace spx {
+namespace host {
+
+constexpr double kPi = 3.14159265358979323846264338327950288;
+
+// w_P^j = exp(-2 pi i j / P), j in [0, P), as interleaved (re, im) floats
+inline std::vector<float> make_twiddles(int P) {
+    std::vector<float> tw(2 * (size_t)P);
+    for (int j = 0; j < P; ++j) {
+        const double a = -2.0 * kPi * (double)j / (double)P;
+        tw[2 * j] = (float)std::cos(a);
+        tw[2 * j + 1] = (float)std::sin(a);
+    }
+    return tw;
+}
+
+// number of 16-wide blocks of the fine window for upsampling factor U:
+// W = 16*blocks >= U + 5 (the +-1/2 px uncertainty of the coarse arg-max plus the
+// 5x5 fit box); 0 for U == 1; -1 when unsupported.
+inline int window_blocks(int U) {
+    if (U < 1) return -1;
+    if (U == 1) return 0;
+    const int blocks = (U + 5 + 15) / 16;
+    return blocks <= 4 ? blocks : -1;
+}
+
+// Interpolation kernels of the two parity classes of the period-P (=128)
+// trigonometric interpolant, sampled on the 64-lag grid of one class:
+//   K_0(t) = 1/64 [1 + 2 sum_{j=1..31} cos(2 pi 2j t / P) + cos(2 pi (P/2) t / P)]
+//   K_1(t) = 2/64 sum_{j odd in 1..P/2-1} cos(2 pi j t / P)
+// (the Nyquist bin is split between +-P/2, as oracle.upsampled_cc does).
+inline double class_kernel(int c, int P, double t) {
+    double s = 0.0;
+    if (c == 0) {
+        s = 1.0 + std::cos(kPi * t);
+        for (int k = 2; k < P / 2; k += 2) s += 2.0 * std::cos(2.0 * kPi * k * t / P);
+    } else {
+        for (int k = 1; k < P / 2; k += 2) s += 2.0 * std::cos(2.0 * kPi * k * t / P);
+    }
+    return s / (double)(P / 2);
+}
+
+// ktab[c][a][m] = K_c( -(a - W/2)/U - (m - 32) ),  c in {0,1}, a in [0,W), m in [0,64)
+inline std::vector<float> make_ktab(int P, int U, int W) {
+    std::vector<float> k(2 * (size_t)W * 64);
+    for (int c = 0; c < 2; ++c)
+        for (int a = 0; a < W; ++a)
+            for (int m = 0; m < 64; ++m) {
+                const double t = -(double)(a - W / 2) / (double)U - (double)(m - 32);
+                k[((size_t)c * W + a) * 64 + m] = (float)class_kernel(c, P, t);
+            }
+    return k;
+}
+
+}  // namespace host
+}  // namespace spx

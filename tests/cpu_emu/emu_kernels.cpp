@@ -1,0 +1,72 @@
+// TEST INFRASTRUCTURE ONLY: runs the kernels of subpixal_amd/csrc/spx_kernels.h on
+// CPU threads (spx_rt_emu.h) so tests can check their logic without a GPU.
+#include "spx_rt_emu.h"
+#include "spx_kernels.h"
+#include "spx_aux_kernels.h"
+#include "spx_tables.h"
+
+using namespace spx;
+
+extern "C" int emu_lds_bytes(int U) {
+    int wb = host::window_blocks(U);
+    return Lds<2>::total(wb > 0 ? 16 * wb : 0);
+}
+
+extern "C" int emu_pair(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
+                        int U, int cc_type, double* out, int* status) {
+    if (ny < 5 || nx < 5 || ny > 64 || nx > 64) return -1;
+    const int wb = host::window_blocks(U);
+    if (wb < 0) return -2;
+    std::vector<float> tw = host::make_twiddles(128);
+    std::vector<float> kt;
+    if (wb > 0) kt = host::make_ktab(128, U, 16 * wb);
+    const cf* twp = reinterpret_cast<const cf*>(tw.data());
+    const float* ktp = kt.empty() ? nullptr : kt.data();
+    auto run = [&](auto fn) { rt::launch(nbatch, kThreads, fn); };
+    switch (wb) {
+    case 0: run([&] { pair_kernel<2, 0>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 1: run([&] { pair_kernel<2, 1>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 2: run([&] { pair_kernel<2, 2>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 3: run([&] { pair_kernel<2, 3>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    default: run([&] { pair_kernel<2, 4>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    }
+    return 0;
+}
+
+extern "C" int emu_disp5(const float* ref, const float* im4, int64_t nbatch, int ny, int nx,
+                         int cc_type, float* icc, double* out, int* status) {
+    if (ny < 3 || nx < 3 || ny > 64 || nx > 64) return -1;
+    std::vector<float> tw = host::make_twiddles(128);
+    const cf* twp = reinterpret_cast<const cf*>(tw.data());
+    rt::launch(nbatch, kThreads,
+               [&] { disp5_kernel<2>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status); });
+    return 0;
+}
+
+extern "C" int emu_find_peak(const double* image, const uint8_t* mask, const double* guess,
+                             int64_t nbatch, int ny, int nx, int wx, int wy, int sbx, int sby,
+                             double* out, int* status) {
+    if ((int64_t)wx * wy > kPeakMaxFitPoints) return -2;
+    rt::launch(nbatch, kThreads, [&] {
+        find_peak_kernel(image, mask, guess, nbatch, ny, nx, wx, wy, sbx, sby, out, status);
+    });
+    return 0;
+}
+
+extern "C" int emu_gather(const float* frame, const uint8_t* fmask, int fny, int fnx,
+                          const int32_t* boxes, int64_t nbatch, int tny, int tnx, float fill,
+                          float* tiles) {
+    const int64_t blocks = (nbatch * tny * tnx + 255) / 256;
+    rt::launch(blocks < 8 ? blocks : 8, 256, [&] {
+        gather_cutouts_kernel(frame, fmask, fny, fnx, boxes, nbatch, tny, tnx, fill, tiles);
+    });
+    return 0;
+}
+
+extern "C" int emu_gen_pairs(uint64_t seed, int64_t first, int64_t nbatch, int n, float slo,
+                             float shi, float maxshift, float* ref, float* img, double* truth) {
+    rt::launch(nbatch, 256, [&] {
+        gen_pairs_kernel(seed, first, nbatch, n, slo, shi, maxshift, ref, img, truth);
+    });
+    return 0;
+}

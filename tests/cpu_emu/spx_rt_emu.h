@@ -1,0 +1,149 @@
+// TEST INFRASTRUCTURE ONLY -- CPU logic-check build of the HIP kernels.
+//
+// Provides the names of subpixal_amd/csrc/spx_rt_hip.h on a CPU: one std::thread
+// per work-item, std::barrier for the workgroup barrier, per-wave barriers for
+// wave-collectives (shuffles, MFMA), one static buffer for the LDS.  It lets the
+// unit tests (and ASan/UBSan) run the very same kernel source that hipcc
+// compiles for gfx950, to check index arithmetic before a kernel touches a GPU.
+// It is never linked into the product library and is orders of magnitude slower.
+#pragma once
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+namespace spx {
+namespace rt {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SPX_DEVICE inline __attribute__((always_inline))
+#define SPX_KERNEL(nthreads) extern "C"
+#define SPX_TKERNEL(nthreads)
+#define SPX_STATIC_LDS(type, name, count) static type name[count]
+#define SPX_DYN_LDS(name) unsigned char* name = ::spx::rt::emu().lds
+
+struct WaveState {
+    std::unique_ptr<std::barrier<>> bar;
+    float fa[64];
+    float fb[64];
+    int ia[64];
+    double da[64];
+};
+
+struct EmuState {
+    alignas(16) unsigned char lds[160 * 1024];
+    std::unique_ptr<std::barrier<>> block_bar;
+    std::vector<WaveState> waves;
+    int nthreads = 0;
+    int64_t nblocks = 0;
+};
+
+inline EmuState& emu() {
+    static EmuState s;
+    return s;
+}
+
+struct ThreadCtx {
+    int tid = 0;
+    int64_t bid = 0;
+};
+inline ThreadCtx& ctx() {
+    static thread_local ThreadCtx c;
+    return c;
+}
+
+SPX_DEVICE int thread_id() { return ctx().tid; }
+SPX_DEVICE int64_t block_id() { return ctx().bid; }
+SPX_DEVICE int64_t grid_size() { return emu().nblocks; }
+SPX_DEVICE void block_sync() { emu().block_bar->arrive_and_wait(); }
+
+inline WaveState& my_wave() { return emu().waves[ctx().tid >> 6]; }
+SPX_DEVICE void wave_sync() { my_wave().bar->arrive_and_wait(); }
+
+SPX_DEVICE float shfl_xor(float v, int m) {
+    WaveState& w = my_wave();
+    int lane = ctx().tid & 63;
+    w.fa[lane] = v;
+    w.bar->arrive_and_wait();
+    float r = w.fa[lane ^ m];
+    w.bar->arrive_and_wait();
+    return r;
+}
+SPX_DEVICE int shfl_xor(int v, int m) {
+    WaveState& w = my_wave();
+    int lane = ctx().tid & 63;
+    w.ia[lane] = v;
+    w.bar->arrive_and_wait();
+    int r = w.ia[lane ^ m];
+    w.bar->arrive_and_wait();
+    return r;
+}
+
+SPX_DEVICE double shfl_xor(double v, int m) {
+    WaveState& w = my_wave();
+    int lane = ctx().tid & 63;
+    w.da[lane] = v;
+    w.bar->arrive_and_wait();
+    double r = w.da[lane ^ m];
+    w.bar->arrive_and_wait();
+    return r;
+}
+
+// v_mfma_f32_16x16x4_f32 (cdna_hip_programming.md section 3): A[i=l&15][k=l>>4],
+// B[k=l>>4][j=l&15], D[row=4*(l>>4)+r][col=l&15]; k-ordered fmaf chain.
+SPX_DEVICE f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
+    WaveState& w = my_wave();
+    int lane = ctx().tid & 63;
+    w.fa[lane] = a;
+    w.fb[lane] = b;
+    w.bar->arrive_and_wait();
+    int col = lane & 15;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k)
+            acc = std::fmaf(w.fa[k * 16 + row], w.fb[k * 16 + col], acc);
+        d[r] = acc;
+    }
+    w.bar->arrive_and_wait();
+    return d;
+}
+
+// Run `body()` as a grid of `nblocks` workgroups of `nthreads` work-items,
+// one workgroup at a time.
+inline void launch(int64_t nblocks, int nthreads, const std::function<void()>& body) {
+    EmuState& s = emu();
+    s.nthreads = nthreads;
+    s.nblocks = nblocks;
+    int nwaves = (nthreads + 63) / 64;
+    s.waves.clear();
+    s.waves.resize(nwaves);
+    for (int w = 0; w < nwaves; ++w) {
+        int lanes = std::min(64, nthreads - 64 * w);
+        s.waves[w].bar = std::make_unique<std::barrier<>>(lanes);
+    }
+    s.block_bar = std::make_unique<std::barrier<>>(nthreads);
+    for (int64_t b = 0; b < nblocks; ++b) {
+        std::memset(s.lds, 0xCD, sizeof(s.lds));   // poison: LDS is uninitialised on a GPU
+        std::vector<std::thread> th;
+        th.reserve(nthreads);
+        for (int t = 0; t < nthreads; ++t) {
+            th.emplace_back([&, t, b]() {
+                ctx().tid = t;
+                ctx().bid = b;
+                body();
+            });
+        }
+        for (auto& t : th) t.join();
+    }
+}
+
+}  // namespace rt
+}  // namespace spx

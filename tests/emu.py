@@ -1,0 +1,96 @@
+"""ctypes access to the CPU logic-check build of the kernels (tests/cpu_emu).
+TEST INFRASTRUCTURE: runs the same kernel source hipcc compiles, on CPU threads."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, 'tests', 'cpu_emu', 'libspx_emu.so')
+_fp = ctypes.POINTER(ctypes.c_float)
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_bp = ctypes.POINTER(ctypes.c_uint8)
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        srcs = [os.path.join(ROOT, 'tests', 'cpu_emu', f) for f in ('emu_kernels.cpp', 'spx_rt_emu.h')]
+        srcs += [os.path.join(ROOT, 'subpixal_amd', 'csrc', f)
+                 for f in ('spx_kernels.h', 'spx_aux_kernels.h', 'spx_tables.h')]
+        if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+            subprocess.check_call(['make', '-C', os.path.join(ROOT, 'subpixal_amd', 'csrc'), 'emu'])
+        _lib = ctypes.CDLL(LIB)
+    return _lib
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def pair(ref, img, upsample=1, cc=0):
+    ref = np.ascontiguousarray(ref, np.float32)
+    img = np.ascontiguousarray(img, np.float32)
+    n = ref.shape[0]
+    out = np.zeros((n, 2))
+    st = np.zeros(n, np.int32)
+    rc = lib().emu_pair(_p(ref, _fp), _p(img, _fp), ctypes.c_int64(n), ref.shape[1], ref.shape[2],
+                        int(upsample), int(cc), _p(out, _dp), _p(st, _ip))
+    assert rc == 0, rc
+    return out, st
+
+
+def disp5(ref, im4, cc=1):
+    ref = np.ascontiguousarray(ref, np.float32)
+    im4 = np.ascontiguousarray(im4, np.float32)
+    n, ny, nx = ref.shape
+    out = np.zeros((n, 2))
+    st = np.zeros(n, np.int32)
+    icc = np.zeros((n, 2 * ny, 2 * nx), np.float32)
+    rc = lib().emu_disp5(_p(ref, _fp), _p(im4, _fp), ctypes.c_int64(n), ny, nx, int(cc),
+                         _p(icc, _fp), _p(out, _dp), _p(st, _ip))
+    assert rc == 0, rc
+    return out, st, icc
+
+
+def find_peak(images, guesses=None, fit=(5, 5), search=(0, 0), masks=None):
+    images = np.ascontiguousarray(images, np.float64)
+    n, ny, nx = images.shape
+    if masks is not None:
+        masks = np.ascontiguousarray(masks, np.uint8)
+    if guesses is not None:
+        guesses = np.ascontiguousarray(guesses, np.float64)
+    out = np.zeros((n, 2))
+    st = np.zeros(n, np.int32)
+    rc = lib().emu_find_peak(_p(images, _dp), _p(masks, _bp), _p(guesses, _dp), ctypes.c_int64(n),
+                             ny, nx, fit[0], fit[1], search[0], search[1], _p(out, _dp), _p(st, _ip))
+    assert rc == 0, rc
+    return out, st
+
+
+def gather(frame, fmask, boxes, tny, tnx, fill):
+    frame = np.ascontiguousarray(frame, np.float32)
+    boxes = np.ascontiguousarray(boxes, np.int32)
+    if fmask is not None:
+        fmask = np.ascontiguousarray(fmask, np.uint8)
+    n = boxes.shape[0]
+    tiles = np.zeros((n, tny, tnx), np.float32)
+    rc = lib().emu_gather(_p(frame, _fp), _p(fmask, _bp), frame.shape[0], frame.shape[1],
+                          boxes.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.c_int64(n),
+                          tny, tnx, ctypes.c_float(fill), _p(tiles, _fp))
+    assert rc == 0
+    return tiles
+
+
+def gen_pairs(seed, first, count, n, slo, shi, maxshift):
+    ref = np.zeros((count, n, n), np.float32)
+    img = np.zeros_like(ref)
+    truth = np.zeros((count, 2))
+    rc = lib().emu_gen_pairs(ctypes.c_uint64(seed), ctypes.c_int64(first), ctypes.c_int64(count), n,
+                             ctypes.c_float(slo), ctypes.c_float(shi), ctypes.c_float(maxshift),
+                             _p(ref, _fp), _p(img, _fp), _p(truth, _dp))
+    assert rc == 0
+    return ref, img, truth

@@ -1,0 +1,122 @@
+"""The kernel SOURCE (subpixal_amd/csrc/*.h) run on CPU threads by the logic-check
+harness (tests/cpu_emu) against the oracle and the reference goldens.  This checks
+index arithmetic / algorithm, not the GPU: the parity tests proper are the
+`-m gpu` tests in test_gpu_parity.py, which call the real library."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import datagen
+import emu
+from oracle import subpixal_oracle as orc
+
+
+def test_pair_mode_vs_oracle():
+    ref, img, truth = datagen.pair_batch(3, 2, 64)
+    for up, tol in ((1, 5e-6), (2, 2e-5), (10, 1e-4)):
+        got, st = emu.pair(ref, img, up)
+        exp, est = orc.xcorr_refine_batch(ref, img, up)
+        assert np.max(np.abs(got - exp)) < tol, (up, np.max(np.abs(got - exp)))
+        assert np.array_equal(st, est)
+
+
+def test_pair_mode_shapes_and_cc_types():
+    rng = np.random.default_rng(1)
+    for (ny, nx) in ((20, 31), (64, 40), (5, 6)):
+        for cc, name in ((0, 'CC'), (1, 'NCC'), (2, 'ZNCC')):
+            s = min(ny, nx)
+            r, i = datagen.pair_set(ny, nx, rng.uniform(-1, 1), rng.uniform(-1, 1),
+                                    max(0.8, s / 12), 1.3, np.float32)
+            i = i.copy()
+            i[np.abs(i) < 1e-3] = 0
+            got, st = emu.pair(r[None], i[None], 3, cc)
+            st2 = []
+            e = orc.xcorr_refine(r, i, 3, name, _status=st2)
+            assert np.max(np.abs(got[0] - np.array(e))) < 1e-4
+            assert st[0] == st2[-1]
+
+
+def test_disp5_vs_reference_goldens(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'find_displacement.npz'))
+    sel = [i for i in range(len(g['dx']))
+           if g['dtype'][i] == 0 and max(g['ny'][i], g['nx'][i]) <= 64][::17]
+    assert len(sel) >= 8
+    for i in sel:
+        ny, nx = int(g['ny'][i]), int(g['nx'][i])
+        ims = datagen.dither_set(ny, nx, g['tx'][i], g['ty'][i], g['sigma'][i], g['amp'][i],
+                                 np.float32, int(g['noise_seed'][i]), g['noise_level'][i],
+                                 int(g['zero_mode'][i]))
+        out, st, icc = emu.disp5(ims[0][None], np.stack(ims[1:])[None], int(g['cc_type'][i]))
+        assert abs(out[0, 0] - g['dx'][i]) < 2e-5 and abs(out[0, 1] - g['dy'][i]) < 2e-5
+        assert int(np.argmax(icc[0])) == int(g['icc_argmax'][i])
+        assert abs(float(icc[0].max()) - g['icc_max'][i]) <= 2e-6 * abs(g['icc_max'][i])
+
+
+def test_find_peak_kernel_vs_reference_goldens(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'find_peak.npz'))
+    meta = json.loads(str(g['meta_json']))
+    picked = list(range(3, len(meta['cases']), 61)) + [451, 458, 497, 500, 505, 517]
+    for k in sorted(set(picked)):
+        case = meta['cases'][k]
+        if case['degenerate']:      # sign of det decided by lstsq rounding noise
+            continue
+        kw = case['kwargs']
+        img = g['img_%03d' % k]
+        ny, nx = img.shape
+        fit = kw.get('peak_fit_box', 5)
+        fit = tuple(fit) if isinstance(fit, list) else (fit, fit)
+        sb = kw.get('peak_search_box', None)
+        if sb == 'fitbox':
+            sb = fit
+        elif sb == 'off':
+            sb = None
+        elif sb == 'all':
+            sb = (ny, nx)
+        if sb is None:
+            sb = (0, 0)
+        elif isinstance(sb, list):
+            sb = tuple(sb)
+        elif isinstance(sb, int):
+            sb = (sb, sb)
+        guess = None
+        if 'xmax' in kw:
+            guess = np.array([[kw['xmax'], kw['ymax']]])
+        else:
+            sb = (0, 0)
+        mask = g['mask_%03d' % k][None] if case['has_mask'] else None
+        out, st = emu.find_peak(img[None], guess, fit, sb, mask)
+        exp = case['expected']
+        assert abs(out[0, 0] - exp[0]) < 1e-7 and abs(out[0, 1] - exp[1]) < 1e-7, (k, kw, out, exp)
+
+
+def test_gather_cutouts_logic():
+    rng = np.random.default_rng(3)
+    frame = rng.standard_normal((40, 50)).astype(np.float32)
+    frame[5, 7] = np.nan
+    frame[6, 8] = np.inf
+    fmask = np.zeros(frame.shape, np.uint8)
+    fmask[10:12, 20:22] = 1
+    boxes = np.array([[2, 3, 16, 12], [-4, -2, 16, 16], [44, 35, 10, 9], [18, 8, 7, 7]], np.int32)
+    tiles = emu.gather(frame, fmask, boxes, 16, 16, -1.0)
+    for b, (x0, y0, w, h) in enumerate(boxes):
+        exp = np.zeros((16, 16), np.float32)
+        for ty in range(h):
+            for tx in range(w):
+                fy, fx = y0 + ty, x0 + tx
+                v = -1.0
+                if 0 <= fy < 40 and 0 <= fx < 50 and not fmask[fy, fx] and np.isfinite(frame[fy, fx]):
+                    v = frame[fy, fx]
+                exp[ty, tx] = v
+        np.testing.assert_array_equal(tiles[b], exp)
+
+
+def test_generator_logic():
+    from subpixal_amd.synth import pair_params
+    ref, img, truth = emu.gen_pairs(123, 5, 3, 32, 3.0, 4.0, 3.0)
+    tx, ty, sg, am = pair_params(123, 5, 3, 3.0, 4.0, 3.0)
+    np.testing.assert_allclose(truth, np.stack([tx, ty], 1), atol=1e-15)
+    for k in range(3):
+        r, i = datagen.pair_set(32, 32, tx[k], ty[k], sg[k], am[k], np.float64)
+        assert np.max(np.abs(ref[k] - r)) < 1e-5 and np.max(np.abs(img[k] - i)) < 1e-5
