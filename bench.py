@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on its config[1]:
+cutout cross-correlations/sec, 64x64 px cutout pairs, upsample=10, 1e5 pairs per GPU
+resident in HBM, on N MI355X of one node (one process per GPU, weak scaling).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (spx_xcorr_refine_f32: FFT cross-correlation ->
+arg-max -> MFMA upsampled-DFT refine -> 5x5 quadratic fit) over the rank's whole batch,
+followed -- when N > 1 -- by the RCCL gather of the per-cutout (dx, dy) to rank 0.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+PAIRS_PER_GPU = 100000          # BASELINE.json configs[1]
+TILE = 64
+UPSAMPLE = 10
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic HBM bytes per pair: two float32 tiles in, (dx,dy) float64 + int32 status out
+BYTES_PER_PAIR = 2 * TILE * TILE * 4 + 16 + 4
+
+
+# ---------------------------------------------------------------------------
+# CPU baseline ("port"): the oracle's restatement of the reference's own per-source
+# path cc.find_displacement (cc.py:21-95: 4 fftconvolve cross-correlations of 64x64
+# float32 cutouts + interlace + find_peak), timed on the host cores of this box.
+# ---------------------------------------------------------------------------
+def _cpu_worker(args):
+    seed, count = args
+    import numpy as np
+    import datagen
+    from oracle import subpixal_oracle as orc
+    ref, im4, _ = datagen.dither_batch(seed, 8, TILE)
+    orc.find_displacement(ref[0], *im4[0], cc_type='NCC')          # warm
+    t0 = time.perf_counter()
+    for k in range(count):
+        j = k % 8
+        orc.find_displacement(ref[j], im4[j, 0], im4[j, 1], im4[j, 2], im4[j, 3], cc_type='NCC')
+    return count, time.perf_counter() - t0
+
+
+def cpu_baseline(per_core=600):
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    ctx = mp.get_context('fork')
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(100 + i, per_core) for i in range(cores)])
+    wall = time.perf_counter() - t0
+    busy = max(r[1] for r in res)
+    total = sum(r[0] for r in res)
+    return {
+        'value': 4.0 * total / busy,
+        'unit': 'cross-correlations/s',
+        'cores': cores,
+        'kind': 'port',
+        'sample': ('oracle.find_displacement (reference cc.py:21-95 restated: 4 cross-correlations '
+                   '+ 2x interlace + find_peak per call, NCC, 64x64 float32) x %d calls on each of '
+                   '%d processes; rate = 4*calls / slowest process time (%.1f s, wall %.1f s)'
+                   % (per_core, cores, busy, wall)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--pairs', type=int, default=PAIRS_PER_GPU)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        args.gpus = world
+
+    # CPU baseline first (fork pool), before this process touches the GPU
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    import torch
+    import torch.distributed as dist
+    import subpixal_amd
+    from subpixal_amd import synth, dist as spx_dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    n_local = args.pairs
+    n_total = n_local * world
+    # inputs generated on the device, resident in HBM before the timed region
+    ref, img, truth = synth.gaussian_pairs(n_local, TILE, seed=20261003,
+                                           first_index=rank * n_local, dev=local_rank)
+    torch.cuda.synchronize()
+
+    def step():
+        d = subpixal_amd.xcorr_refine_batch(ref, img, upsample=UPSAMPLE)
+        g = spx_dist.gather_shifts(d, n_total=n_total, dst=0) if world > 1 else d
+        return d, g
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        d, g = step()
+    torch.cuda.synchronize()
+    # sanity: the thing being timed is the correct answer
+    err = float((d - truth).abs().max())
+    assert err < 1e-3, "shifts are wrong (%g px): refusing to time" % err
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()                 # torch's current stream == the launch stream
+        d = subpixal_amd.xcorr_refine_batch(ref, img, upsample=UPSAMPLE)
+        ev[k][1].record()
+        if world > 1:
+            spx_dist.gather_shifts(d, n_total=n_total, dst=0)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+
+    if rank == 0:
+        value = n_total * args.steps / elapsed
+        achieved = n_local * BYTES_PER_PAIR / (kern_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'cutout cross-correlations/sec (64x64 px, upsample=10)',
+            'value': value,
+            'unit': 'cross-correlations/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'BASELINE.json configs[1]: %d 64x64 Gaussian-spot cutout pairs per GPU, '
+                            'upsample=10, inputs resident in HBM' % n_local,
+                'pairs_per_gpu': n_local, 'tile': TILE, 'upsample': UPSAMPLE, 'cc_type': 'CC',
+                'parallelism': 'batch sharded over %d GPU(s); gather of (dx,dy) to rank 0' % world,
+            },
+            'roofline': {
+                'bound': 'hbm',
+                'achieved': achieved,
+                'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS,
+                'traffic': None,
+                'kernel': 'spx::pair_kernel<2,1>',
+                'kernel_ms': kern_ms,
+                'bytes_per_pair': BYTES_PER_PAIR,
+                'pairs_per_launch': n_local,
+            },
+            'max_abs_err_px_vs_truth': err,
+        }
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -138,7 +138,7 @@ size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx) {
 int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
                          int upsample, int cc_type, double* out_dxdy, int32_t* out_status,
                          void* stream) {
-    if (nbatch < 0 || !out_dxdy || (nbatch > 0 && (!ref || !img)))
+    if (nbatch < 0 || (nbatch > 0 && (!ref || !img || !out_dxdy)))
         return fail(SPX_E_ARG, "null pointer or negative batch");
     if (ny < 5 || nx < 5 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
         return fail(SPX_E_SHAPE, "pair mode supports cutouts of 5..64 pixels per side");
@@ -165,7 +165,7 @@ int spx_find_displacement5_f32(const float* ref, const float* im4, int64_t nbatc
                                int nx, int cc_type, double* out_dxdy, int32_t* out_status,
                                float* out_icc, void* workspace, size_t workspace_bytes,
                                void* stream) {
-    if (nbatch < 0 || !out_dxdy || (nbatch > 0 && (!ref || !im4)))
+    if (nbatch < 0 || (nbatch > 0 && (!ref || !im4 || !out_dxdy)))
         return fail(SPX_E_ARG, "null pointer or negative batch");
     if (ny < 3 || nx < 3 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
         return fail(SPX_E_SHAPE, "5-image mode supports cutouts of 3..64 pixels per side");
@@ -193,7 +193,7 @@ int spx_find_displacement5_f32(const float* ref, const float* im4, int64_t nbatc
 int spx_find_peak_f64(const double* image, const uint8_t* mask, const double* guess,
                       int64_t nbatch, int ny, int nx, int fit_wx, int fit_wy, int search_wx,
                       int search_wy, double* out_xy, int32_t* out_status, void* stream) {
-    if (nbatch < 0 || !out_xy || (nbatch > 0 && !image))
+    if (nbatch < 0 || (nbatch > 0 && (!image || !out_xy)))
         return fail(SPX_E_ARG, "null pointer or negative batch");
     if (ny < 1 || nx < 1 || (int64_t)ny * nx > (int64_t)1 << 30)
         return fail(SPX_E_SHAPE, "bad image shape");

@@ -37,6 +37,8 @@ def test_argument_errors_without_gpu():
     assert lib.spx_workspace_bytes_displacement5(10, 64, 64) == 10 * 4 * 64 * 64 * 4
     # argument validation happens before any HIP call
     assert lib.spx_xcorr_refine_f32(None, None, 1, 64, 64, 1, 0, None, None, None) == -1
+    assert lib.spx_xcorr_refine_f32(None, None, 0, 64, 64, 1, 0, None, None, None) == 0
+    assert lib.spx_xcorr_refine_f32(None, None, -1, 64, 64, 1, 0, None, None, None) == -1
     buf = (ctypes.c_double * 4)()
     p = ctypes.cast(buf, ctypes.c_void_p)
     assert lib.spx_xcorr_refine_f32(p, p, 1, 65, 64, 1, 0, p, None, None) == -2
