@@ -6,6 +6,7 @@
 #include "spx_tables.h"
 #include "../../include/subpixal_hip.h"
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -86,12 +87,12 @@ unsigned grid_for(const DeviceTables* t, int64_t nbatch) {
     return (unsigned)(nbatch < cap ? nbatch : cap);
 }
 
-template <int WB>
+template <int WB, int DBG = 0>
 int launch_pair(const DeviceTables* t, const float* ref, const float* img, int64_t nbatch, int ny,
                 int nx, int U, int cc_type, const float* ktab, double* out, int32_t* status,
                 hipStream_t s) {
     const int lds = spx::Lds<2>::total(16 * WB);
-    auto kern = spx::pair_kernel<2, WB>;
+    auto kern = spx::pair_kernel<2, WB, DBG>;
     int rc = allow_lds(kern, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(grid_for(t, nbatch)), dim3(spx::kThreads), lds, s, ref, img,
@@ -160,6 +161,28 @@ int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int
     default: return launch_pair<4>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
     }
 }
+
+#ifdef SPX_PHASE_TIMING
+// Diagnostic library only (`make diag`): the pair kernel (upsample 10) cut short after
+// phase `phase` (1..13, see tools/phase_timing.py); results are invalid.
+int spx_diag_pair_phase(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
+                        int phase, double* out_dxdy, int32_t* out_status, void* stream) {
+    DeviceTables* t = nullptr;
+    int rc = current_tables(&t);
+    if (rc) return rc;
+    const float* ktab = nullptr;
+    rc = ktab_for(t, 10, &ktab);
+    if (rc) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define SPX_PH(k) case k: return launch_pair<1, k>(t, ref, img, nbatch, ny, nx, 10, 0, ktab, out_dxdy, out_status, s);
+    switch (phase) {
+        SPX_PH(0) SPX_PH(1) SPX_PH(2) SPX_PH(3) SPX_PH(4) SPX_PH(5) SPX_PH(6) SPX_PH(7)
+        SPX_PH(8) SPX_PH(9) SPX_PH(10) SPX_PH(11) SPX_PH(12) SPX_PH(13)
+    }
+#undef SPX_PH
+    return fail(SPX_E_ARG, "bad phase");
+}
+#endif
 
 int spx_find_displacement5_f32(const float* ref, const float* im4, int64_t nbatch, int ny,
                                int nx, int cc_type, double* out_dxdy, int32_t* out_status,

@@ -18,12 +18,17 @@
 // FFT.  Wave w owns class (w>>1, w&1) and keeps its 64x64 complex points in
 // registers as an 8x8 tile per lane; a 2-D FFT is two register rounds
 // (radix-8 in y and x) with ONE lane<->register transposition through LDS in
-// between.  ref and img are packed as z = ref + i*img; the cross-power spectrum
-// S = R conj(I) needs Z[k] and Z[-k], which live in the same class.  The inverse
-// runs the same rounds backwards and leaves, per class, the REAL plane
-//   d_c[l] = Re sum_{k in class c} S[k] e^{+2 pi i k l / P},   l in [0,64)^2,
-// in LDS.  The linear cross-correlation at lag l in [-32,31]^2 is
-//   cc[l] = P^-2 sum_c (-1)^(c . [l<0]) d_c[l mod 64]
+// between.  The two real images are packed as z = ref + i*flip(img) (flip = both
+// axes reversed, exactly the operand of the reference's fftconvolve(ref,
+// im[::-1, ::-1]), cc.py:114): with Z = FFT(z),
+//   IFFT(Z^2) = (ref*ref - fimg*fimg) + 2i (ref * fimg)       (* = convolution)
+// so the cross-correlation is Im(IFFT(Z^2))/2 and the spectral product is a plain
+// element-wise complex SQUARE -- no Z[k] / Z[-k] unpacking, no data exchange.  The
+// inverse runs the same rounds backwards and leaves, per class, the REAL plane
+//   d_c[l] = 1/2 Im sum_{k in class c} Z[k]^2 e^{+2 pi i k l / P},   l in [0,64)^2,
+// in LDS (real because each class is closed under k -> -k).  The full linear
+// convolution at index l in [0,127)^2 (lag = l - (n-1)) is
+//   conv[l] = P^-2 sum_c (-1)^(c . [l>=64]) d_c[l mod 64]
 // and its trigonometric interpolant (the upsample=U mode) is
 //   F(t)  = P^-2 sum_c sum_m K_cy(ty-my) d_c[m] K_cx(tx-mx),
 // two small real matrix products per class, done with v_mfma_f32_16x16x4_f32.
@@ -253,8 +258,16 @@ SPX_DEVICE PeakResult quad_fit_5x5(const double* d, int x1, int y1, int imax, in
     return r;
 }
 
+// the w_P^j table lives in LDS for the whole life of the workgroup
+template <int C> SPX_DEVICE void load_twiddles(unsigned char* lds, const cf* __restrict__ tw_g) {
+    typedef Lds<C> L;
+    cf* tw = reinterpret_cast<cf*>(lds + L::TW_OFF);
+    for (int i = rt::thread_id(); i < L::P; i += kThreads) tw[i] = tw_g[i];
+    rt::block_sync();
+}
+
 // ---------------------------------------------------------------------------
-// Stage one (ref, img) pair into the LDS input planes, zero padded to 64x64,
+// Stage one (ref, flipped img) pair into the LDS input planes, zero padded to 64x64,
 // with cc.py:131-156's normalisation (pool = this one image, or the `npool`
 // images of the 5-image mode whose statistics the caller passes in).
 // ---------------------------------------------------------------------------
@@ -263,20 +276,52 @@ struct NormStats {      // what _normalize applies: im = (im - mean)/std on im !
     int active;         // 0: plain CC
 };
 
+// ssq[0] += sum ref^2, ssq[1] += sum img^2 over this thread's pixels (as staged).
 template <int C>
 SPX_DEVICE void stage_pair(unsigned char* lds, const float* __restrict__ ref,
                            const float* __restrict__ img, int ny, int nx,
-                           const NormStats& ns) {
+                           const NormStats& ns, double (&ssq)[2]) {
     typedef Lds<C> L;
+    float sr = 0.0f, sm = 0.0f;
     const int tid = rt::thread_id();
     float* zre = reinterpret_cast<float*>(lds + L::R_OFF);
     float* zim = zre + 64 * L::ZS;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(img)) & 15) == 0;
+    if (ny == 64 && nx == 64 && aligned) {
+        // full tiles: 16-byte global loads (coalesced 1 KiB per wave-instruction) and
+        // 16-byte LDS stores; the image row is read back to front for the flip
+        const f32x4* r4 = reinterpret_cast<const f32x4*>(ref);
+        const f32x4* m4 = reinterpret_cast<const f32x4*>(img);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * kThreads;            // 1024 float4 per image
+            const int y = idx >> 4, x4 = (idx & 15) << 2;
+            f32x4 r = r4[idx];
+            const f32x4 t = m4[(63 - y) * 16 + (15 - (idx & 15))];
+            f32x4 m = f32x4{t[3], t[2], t[1], t[0]};
+            if (ns.active) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (m[e] != 0.0f) { m[e] = m[e] - ns.im_mean; m[e] = m[e] / ns.im_std; }
+                    r[e] = r[e] - ns.ref_mean;
+                    r[e] = r[e] / ns.ref_std;
+                }
+            }
+            *reinterpret_cast<f32x4*>(zre + y * L::ZS + x4) = r;
+            *reinterpret_cast<f32x4*>(zim + y * L::ZS + x4) = m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sr += r[e] * r[e]; sm += m[e] * m[e]; }
+        }
+        ssq[0] = (double)sr;
+        ssq[1] = (double)sm;
+        return;
+    }
     for (int idx = tid; idx < 64 * 64; idx += kThreads) {
         const int y = idx >> 6, x = idx & 63;
         float r = 0.0f, m = 0.0f;
         if (y < ny && x < nx) {
             r = ref[(int64_t)y * nx + x];
-            m = img[(int64_t)y * nx + x];
+            m = img[(int64_t)(ny - 1 - y) * nx + (nx - 1 - x)];     // flipped: cc.py:114
             if (ns.active) {
                 if (m != 0.0f) {           // cc.py:144-148: masked pixels only
                     m = m - ns.im_mean;
@@ -288,14 +333,49 @@ SPX_DEVICE void stage_pair(unsigned char* lds, const float* __restrict__ ref,
         }
         zre[y * L::ZS + x] = r;
         zim[y * L::ZS + x] = m;
+        sr += r * r;
+        sm += m * m;
     }
+    ssq[0] = (double)sr;
+    ssq[1] = (double)sm;
 }
+
+// Z = FFT(ref + i*bal*flip(img)) is squared, so the cross term 2 ref*img is rounded
+// relative to ref*ref + img*img: keep the two images at comparable amplitude.  `bal`
+// is an exact power of two near sqrt(sum ref^2 / sum img^2) (1 when either is zero);
+// results are multiplied by 1/bal, also exact.  Workgroup-wide; two barriers.
+SPX_DEVICE float balance_factor(unsigned char* lds_scr, double (&ssq)[2]) {
+    block_sum<2>(lds_scr, ssq);
+    if (!(ssq[0] > 0.0) || !(ssq[1] > 0.0)) return 1.0f;
+    const float ratio = (float)sqrt(ssq[0] / ssq[1]);
+    if (!(ratio > 1e-30f && ratio < 1e30f)) return 1.0f;
+    // largest power of two <= ratio: keep the exponent field, clear the mantissa
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, ratio) & 0x7f800000u);
+}
+
+// Diagnostic early exit for phase timing (tools/phase_timing.py, `make diag`): DBG
+// is a template parameter, 0 in the product library, so production code carries none
+// of it.  A stopped variant folds its registers into one float per lane and stores
+// it, which keeps the compiler from deleting the work done so far.
+SPX_DEVICE float fold_tile(cf (&v)[8][8]) {
+    float s = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) s += v[r >> 3][r & 7].x + v[r >> 3][r & 7].y;
+    return s;
+}
+#define SPX_DBG_STOP(k)                                                        \
+    do {                                                                       \
+        if constexpr (DBG == (k)) {                                            \
+            reinterpret_cast<float*>(lds + L::SCR_OFF + 768)[tid & 63] = fold_tile(v); \
+            return true;                                                       \
+        }                                                                      \
+    } while (0)
 
 // ---------------------------------------------------------------------------
 // cc_planes: staged input planes -> the NCLS real class planes d_c in LDS.
 // Caller must have issued a block_sync after staging; ends with a block_sync.
 // ---------------------------------------------------------------------------
-template <int C> SPX_DEVICE void cc_planes(unsigned char* lds) {
+template <int C, int DBG = 0> SPX_DEVICE bool cc_planes(unsigned char* lds, float bal) {
     typedef Lds<C> L;
     static_assert(C == 2, "class decomposition implemented for P = 128");
     const int tid = rt::thread_id();
@@ -315,7 +395,7 @@ template <int C> SPX_DEVICE void cc_planes(unsigned char* lds) {
 #pragma unroll
         for (int x1 = 0; x1 < 8; ++x1) {
             const int a = (l1 + 8 * y1) * L::ZS + l0 + 8 * x1;
-            v[y1][x1] = cf{zre[a], zim[a]};
+            v[y1][x1] = cf{zre[a], bal * zim[a]};
         }
     rt::block_sync();                       // all waves have read the staged input
 
@@ -338,6 +418,7 @@ template <int C> SPX_DEVICE void cc_planes(unsigned char* lds) {
     }
     fft8_y<1>(v);                           // y1 -> kyb
     fft8_x<1>(v);                           // x1 -> kxb
+    SPX_DBG_STOP(2);
     // twiddle w_P^{y0 (cy + C kyb)} w_P^{x0 (cx + C kxb)}
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
@@ -352,6 +433,7 @@ template <int C> SPX_DEVICE void cc_planes(unsigned char* lds) {
         for (int j = 0; j < 8; ++j) v[j][kb] = cmul(v[j][kb], wx);
     }
 
+    SPX_DBG_STOP(3);
     // ---- transposition: (lane (y0,x0), reg (kyb,kxb)) -> (lane (kyb,kxb), reg (y0,x0))
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
@@ -367,53 +449,23 @@ template <int C> SPX_DEVICE void cc_planes(unsigned char* lds) {
         rt::wave_sync();
     }
 
+    SPX_DBG_STOP(4);
     // ---- forward round B: lane = (kyb, kxb), registers (y0, x0) -> (kya, kxa)
     fft8_y<1>(v);
     fft8_x<1>(v);
+    SPX_DBG_STOP(5);
     // now v[kya][kxa] = Z[ky][kx], ky = cy + C*l1 + 8C*kya, kx = cx + C*l0 + 8C*kxa
 
-    // ---- cross-power spectrum S = R conj(I) from Z[k] and Z[-k] (same class)
-    //   Re S = Im(Z[k] Z[-k]) / 2,   Im S = (|Z[k]|^2 - |Z[-k]|^2) / 4
-    {
-        // partner lane / register digits for -k (mod P)
-        const int zy = (cy == 0 && l1 == 0), zx = (cx == 0 && l0 == 0);
-        const int pl1 = cy ? 7 - l1 : (8 - l1) & 7;
-        const int pl0 = cx ? 7 - l0 : (8 - l0) & 7;
-        const int plane_ = pl1 * 8 + pl0;
-        // Two phases through the 16 KiB buffer: partner real parts are parked in
-        // registers, partner imaginary parts are consumed as they arrive.
-        float znre[8][8];
+    // ---- spectral product: W = Z^2 (see the header: Im IFFT(Z^2) = 2 ref*flip(img))
 #pragma unroll
-        for (int r = 0; r < 64; ++r) xch[r * L::XS + lane] = v[r >> 3][r & 7].x;
-        rt::wave_sync();
+    for (int ka = 0; ka < 8; ++ka)
 #pragma unroll
-        for (int ka = 0; ka < 8; ++ka) {
-            const int pka = (7 - ka + zy) & 7;
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                const int pkb = (7 - kb + zx) & 7;
-                znre[ka][kb] = xch[(pka * 8 + pkb) * L::XS + plane_];
-            }
+        for (int kb = 0; kb < 8; ++kb) {
+            const cf a = v[ka][kb];
+            v[ka][kb] = cf{a.x * a.x - a.y * a.y, 2.0f * a.x * a.y};
         }
-        rt::wave_sync();
-#pragma unroll
-        for (int r = 0; r < 64; ++r) xch[r * L::XS + lane] = v[r >> 3][r & 7].y;
-        rt::wave_sync();
-#pragma unroll
-        for (int ka = 0; ka < 8; ++ka) {
-            const int pka = (7 - ka + zy) & 7;
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                const int pkb = (7 - kb + zx) & 7;
-                const cf a = v[ka][kb];
-                const cf b = cf{znre[ka][kb], xch[(pka * 8 + pkb) * L::XS + plane_]};
-                v[ka][kb] = cf{0.5f * (a.x * b.y + a.y * b.x),
-                               0.25f * ((a.x * a.x + a.y * a.y) - (b.x * b.x + b.y * b.y))};
-            }
-        }
-        rt::wave_sync();
-    }
 
+    SPX_DBG_STOP(6);
     // ---- inverse round A': registers (kya, kxa) -> (y0, x0), lane = (kyb, kxb)
     fft8_y<-1>(v);
     fft8_x<-1>(v);
@@ -429,6 +481,7 @@ template <int C> SPX_DEVICE void cc_planes(unsigned char* lds) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j][x0] = cmulc(v[j][x0], wx);
     }
+    SPX_DBG_STOP(7);
     // ---- transposition back: -> lane (y0, x0), registers (kyb, kxb)
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
@@ -443,10 +496,12 @@ template <int C> SPX_DEVICE void cc_planes(unsigned char* lds) {
         }
         rt::wave_sync();
     }
+    SPX_DBG_STOP(8);
     // ---- inverse round B': registers (kyb, kxb) -> (y1, x1)
     fft8_y<-1>(v);
     fft8_x<-1>(v);
-    // class post-twiddle conj(w_P^{8 (cy y1 + cx x1)}); only the real part is kept
+    SPX_DBG_STOP(9);
+    // class post-twiddle conj(w_P^{8 (cy y1 + cx x1)}); half the imaginary part is kept
     rt::block_sync();      // every wave is done with its transposition buffer
     float* plane = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::PLANE_BYTES);
 #pragma unroll
@@ -457,21 +512,27 @@ template <int C> SPX_DEVICE void cc_planes(unsigned char* lds) {
             const cf wx = tw[8 * cx * x1];
             const cf w = cmul(wy, wx);
             const cf a = v[y1][x1];
-            plane[(l1 + 8 * y1) * L::PS + l0 + 8 * x1] = a.x * w.x + a.y * w.y;  // Re(a conj w)
+            plane[(l1 + 8 * y1) * L::PS + l0 + 8 * x1] = 0.5f * (a.y * w.x - a.x * w.y);  // Im(a conj w)/2
         }
     }
     rt::block_sync();
+    return false;
 }
 
-// cross-correlation value at flipped 'same'-window index (qy, qx) of a
-// (ny, nx) cutout: lag l = (n - 1 - q) - n/2  (cc.py:114-126 flips the window).
+// cross-correlation value at flipped 'same'-window index (qy, qx) of a (ny, nx)
+// cutout.  scipy's 'same' crop starts at (n-1)//2 of the full convolution and
+// cc.py:121-126 flips the window, so q <-> convolution index l = (n-1-q) + (n-1)//2
+// (lag l - (n-1) = (n-1-q) - n//2).
+SPX_DEVICE int conv_index(int n, int q) { return (n - 1 - q) + (n - 1) / 2; }
+
 template <int C>
-SPX_DEVICE float window_value(const unsigned char* lds, int ny, int nx, int qy, int qx) {
+SPX_DEVICE float window_value(const unsigned char* lds, int ny, int nx, int qy, int qx,
+                              float out_scale) {
     typedef Lds<C> L;
     const float* planes = reinterpret_cast<const float*>(lds + L::R_OFF);
-    const int ly = (ny - 1 - qy) - ny / 2, lx = (nx - 1 - qx) - nx / 2;
+    const int ly = conv_index(ny, qy), lx = conv_index(nx, qx);
     const int my = ly & 63, mx = lx & 63;
-    const int sy = ly < 0, sx = lx < 0;
+    const int sy = (ly >> 6) & 1, sx = (lx >> 6) & 1;
     float acc = 0.0f;
 #pragma unroll
     for (int c = 0; c < C * C; ++c) {
@@ -479,7 +540,7 @@ SPX_DEVICE float window_value(const unsigned char* lds, int ny, int nx, int qy, 
         const int neg = ((c / C) & sy) ^ ((c % C) & sx);
         acc += neg ? -d : d;
     }
-    return acc * (1.0f / (float)(L::P * L::P));
+    return acc * out_scale;     // out_scale = 1 / (P^2 bal)
 }
 
 // ---------------------------------------------------------------------------
@@ -553,13 +614,18 @@ SPX_DEVICE PeakResult peak_from_argmax(unsigned char* lds_scr, int imax, int jma
 }
 
 // ---------------------------------------------------------------------------
-// Fine (upsampled) window by MFMA.  ktab: float [2][W][64],
-//   ktab[c][a][m] = K_c( -(a - W/2)/U - (m - 32) ),
+// Fine (upsampled) window by MFMA (v_mfma_f32_16x16x4_f32, exact f32).
 //   K_0(t) = 1/64 [1 + 2 sum_{j=1..31} cos(2 pi 2j t / P) + cos(2 pi 64 t / P)],
-//   K_1(t) = 2/64 sum_{j odd, 1..63} cos(2 pi j t / P)                (P = 128).
-// Computes, for fine offsets a', b' in [-W/2, W/2) around flipped coarse index
-// (qyc, qxc):  F[b][a] = cc interpolated at q = U*qc + offset, into fbuf[b*W+a]
-// (note the transposed storage: first index is the x offset).
+//   K_1(t) = 2/64 sum_{j odd, 1..63} cos(2 pi j t / P)                (P = 128)
+// are the interpolation kernels of the two parity classes.  With the window centred
+// on convolution index (lyc, lxc) and both plane axes addressed RELATIVE to it
+// (m = lc + m'', m'' in [-32, 32)), the operands that hold K are the same for every
+// pair, so they come from two lane-major constant tables (spx_tables.h):
+//   kty[c][blk][lane][s]    = K_c(-(16 blk + lj - W/2)/U - (4 s + lk - 32))       stage 1, B
+//   ktx[c][blk][lane][4t+r] = K_c(-(16 blk + lj - W/2)/U - (16 t + 4 lk + r - 32))  stage 2, A
+// (lane = 16 lk + lj).  Computes, for fine offsets a', b' in [-W/2, W/2) around the
+// flipped coarse index (qyc, qxc),  F[b][a] = conv interpolated at q = U*qc + offset,
+// into fbuf[b*W + a] (first index = x offset).
 // ---------------------------------------------------------------------------
 template <int C, int WB>
 SPX_DEVICE void fine_window(unsigned char* lds, const float* __restrict__ ktab,
@@ -573,57 +639,66 @@ SPX_DEVICE void fine_window(unsigned char* lds, const float* __restrict__ ktab,
     const int lk = lane >> 4, lj = lane & 15;
     const float* plane = reinterpret_cast<const float*>(lds + L::R_OFF + wave * L::PLANE_BYTES);
     float* fbuf = reinterpret_cast<float*>(lds + L::R_OFF + L::PLANES_BYTES);
-    // integer lags of the window centre
-    const int lyc = (ny - 1 - qyc) - ny / 2, lxc = (nx - 1 - qxc) - nx / 2;
-    const float* ky = ktab + (size_t)cy * W * 64;
-    const float* kx = ktab + (size_t)cx * W * 64;
+    const int lyc = conv_index(ny, qyc), lxc = conv_index(nx, qxc);
+    // table slices of this lane: [2 (y|x)][2 (class)][WB][64 lanes][16]
+    const f32x4* kty = reinterpret_cast<const f32x4*>(ktab) + ((size_t)(0 * 2 + cy) * WB * 64 + lane) * 4;
+    const f32x4* ktx = reinterpret_cast<const f32x4*>(ktab) + ((size_t)(1 * 2 + cx) * WB * 64 + lane) * 4;
 
-    // stage 1: G^T[mx][a] = sum_m'' plane[(lyc + m'') & 63][mx] * sgn * ky[a][m''+32]
+    // d_c[m] = (-1)^(c floor(m/64)) plane[m mod 64]: the sign of a wrapped row goes
+    // into the K operand of that row, the sign of a wrapped column likewise.
     f32x4 acc[WB][4];
 #pragma unroll
     for (int ab = 0; ab < WB; ++ab)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[ab][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int step = 0; step < 16; ++step) {
-        const int mi = 4 * step + lk;              // table index m''+32
-        const int m = lyc + mi - 32;               // lag of that plane row
-        const int row = m & 63;
-        // d_c[m] = (-1)^(cy * floor(m/64)) plane[m mod 64]
-        const float sgn = (cy && ((m >> 6) & 1)) ? -1.0f : 1.0f;
-        float bfrag[WB];
+    int col[4];
 #pragma unroll
-        for (int ab = 0; ab < WB; ++ab) bfrag[ab] = sgn * ky[(ab * 16 + lj) * 64 + mi];
+    for (int t = 0; t < 4; ++t) col[t] = (lxc + 16 * t + lj - 32) & 63;
+
+    // stage 1: G^T[mx''][a] = sum_my'' plane[(lyc+my'')&63][(lxc+mx'')&63] sgn_y K_cy[a][my'']
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float afrag = plane[row * L::PS + t * 16 + lj];
+    for (int s4 = 0; s4 < 4; ++s4) {
+        f32x4 kb[WB];
 #pragma unroll
-            for (int ab = 0; ab < WB; ++ab)
-                acc[ab][t] = rt::mfma_16x16x4(afrag, bfrag[ab], acc[ab][t]);
+        for (int ab = 0; ab < WB; ++ab) kb[ab] = kty[ab * 64 * 4 + s4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int step = 4 * s4 + e;
+            const int m = lyc + 4 * step + lk - 32;
+            const int row = m & 63;
+            const float sgn = (cy && ((m >> 6) & 1)) ? -1.0f : 1.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float afrag = plane[row * L::PS + col[t]];
+#pragma unroll
+                for (int ab = 0; ab < WB; ++ab)
+                    acc[ab][t] = rt::mfma_16x16x4(afrag, sgn * kb[ab][e], acc[ab][t]);
+            }
         }
     }
-    // stage 2: F^T[b][a] = sum_mx kxs[b][mx] G^T[mx][a]; the accumulator register r
-    // of tile t is the B operand row k' = lane>>4 for mx = 16 t + 4 k' + r.
+    // stage 2: F^T[b][a] = sum_mx'' sgn_x K_cx[b][mx''] G^T[mx''][a]; accumulator register
+    // r of tile t is B-operand row k' = lane>>4 for mx'' = 16 t + 4 k' + r - 32.
     f32x4 f[WB][WB];
 #pragma unroll
     for (int bb = 0; bb < WB; ++bb)
 #pragma unroll
         for (int ab = 0; ab < WB; ++ab) f[bb][ab] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t) {
+        f32x4 ka[WB];
+#pragma unroll
+        for (int bb = 0; bb < WB; ++bb) ka[bb] = ktx[bb * 64 * 4 + t];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int mx = 16 * t + 4 * lk + r;             // raw plane column
-            const int mrel = ((mx - lxc + 32) & 63) - 32;   // m'' in [-32, 31]
-            const int m = lxc + mrel;                        // actual lag
+            const int m = lxc + 16 * t + 4 * lk + r - 32;
             const float sgn = (cx && ((m >> 6) & 1)) ? -1.0f : 1.0f;
 #pragma unroll
-            for (int bb = 0; bb < WB; ++bb) {
-                const float afrag = sgn * kx[(bb * 16 + lj) * 64 + mrel + 32];
+            for (int bb = 0; bb < WB; ++bb)
 #pragma unroll
                 for (int ab = 0; ab < WB; ++ab)
-                    f[bb][ab] = rt::mfma_16x16x4(afrag, acc[ab][t][r], f[bb][ab]);
-            }
+                    f[bb][ab] = rt::mfma_16x16x4(sgn * ka[bb][r], acc[ab][t][r], f[bb][ab]);
         }
+    }
     // sum the 4 classes in fixed order through LDS
     const float scale = 1.0f / (float)(L::P * L::P);
     for (int c = 0; c < C * C; ++c) {
@@ -647,7 +722,7 @@ SPX_DEVICE void fine_window(unsigned char* lds, const float* __restrict__ ktab,
 // Pair kernel: one workgroup per (ref, img) pair.
 //   out[2*pair + {0,1}] = (dx, dy) float64, status[pair]
 // ---------------------------------------------------------------------------
-template <int C, int WB>
+template <int C, int WB, int DBG = 0>
 SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict__ img,
                           int ny, int nx, int U, int cc_type, const cf* __restrict__ tw_g,
                           const float* __restrict__ ktab, double* __restrict__ out,
@@ -655,28 +730,36 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
     typedef Lds<C> L;
     const int tid = rt::thread_id();
     unsigned char* scr = lds + L::SCR_OFF;
-    cf* tw = reinterpret_cast<cf*>(lds + L::TW_OFF);
-    for (int i = tid; i < L::P; i += kThreads) tw[i] = tw_g[i];
-
     const NormStats ns = norm_stats(scr, ref, img, 1, 0, ny, nx, cc_type);
-    stage_pair<C>(lds, ref, img, ny, nx, ns);
-    rt::block_sync();
-    cc_planes<C>(lds);
+    double ssq[2];
+    stage_pair<C>(lds, ref, img, ny, nx, ns, ssq);
+    const float bal = balance_factor(scr, ssq);       // includes the barrier after staging
+    const float oscale = 1.0f / ((float)(L::P * L::P) * bal);
+    if constexpr (DBG == 1) return;
+    if (cc_planes<C, DBG>(lds, bal)) return;
+    if constexpr (DBG == 10) return;
 
     // coarse arg-max over the flipped 'same' window (centroid.py:114-116)
     float bv = -__builtin_inff();
     int bi = 0x7fffffff;
-    for (int idx = tid; idx < ny * nx; idx += kThreads) {
-        const float val = window_value<C>(lds, ny, nx, idx / nx, idx % nx);
-        if (better(val, idx, bv, bi)) { bv = val; bi = idx; }
+    {
+        const int qx = tid & 63;             // nx <= 64: one column per lane
+        if (qx < nx) {
+            for (int qy = tid >> 6; qy < ny; qy += kThreads / 64) {
+                const float val = window_value<C>(lds, ny, nx, qy, qx, oscale);
+                const int idx = qy * nx + qx;
+                if (better(val, idx, bv, bi)) { bv = val; bi = idx; }
+            }
+        }
     }
     block_argmax(scr, bv, bi);
-    int qyc = bi / nx, qxc = bi % nx;
+    int qyc = bi / nx, qxc = bi - (bi / nx) * nx;
+    if constexpr (DBG == 11) { if (tid == 0) out[0] = (double)bi; return; }
 
     PeakResult pk;
     if constexpr (WB == 0) {
         pk = peak_from_argmax(scr, qxc, qyc, nx, ny, [&](int x, int y) {
-            return window_value<C>(lds, ny, nx, y, x);
+            return window_value<C>(lds, ny, nx, y, x, oscale);
         });
     } else {
         constexpr int W = 16 * (WB > 0 ? WB : 1);
@@ -686,6 +769,7 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
         bool inside = false;
         for (int iter = 0; iter < 4; ++iter) {
             fine_window<C, (WB > 0 ? WB : 1)>(lds, ktab, ny, nx, qyc, qxc);
+            if constexpr (DBG == 12) { if (tid == 0) out[0] = (double)fbuf[0]; return; }
             // arg-max over the part of the window inside the virtual image
             const int fx0 = U * qxc - W / 2, fy0 = U * qyc - W / 2;
             float fv = -__builtin_inff();
@@ -699,6 +783,7 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
                 }
             }
             block_argmax(scr, fv, fi);
+            if constexpr (DBG == 13) { if (tid == 0) out[0] = (double)fi; return; }
             const int a = fi / W, b = fi % W;
             jmax = fy0 + a;
             imax = fx0 + b;
@@ -734,16 +819,17 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
     }
 }
 
-template <int C, int WB>
+template <int C, int WB, int DBG = 0>
 SPX_TKERNEL(256) void pair_kernel(const float* __restrict__ ref, const float* __restrict__ img,
                                   int64_t nbatch, int ny, int nx, int U, int cc_type,
                                   const cf* __restrict__ tw_g, const float* __restrict__ ktab,
                                   double* __restrict__ out, int* __restrict__ status) {
     SPX_DYN_LDS(lds);
+    load_twiddles<C>(lds, tw_g);
     const int64_t stride = (int64_t)ny * nx;
     for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
-        pair_body<C, WB>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, tw_g, ktab,
-                         out + 2 * p, status ? status + p : nullptr, lds);
+        pair_body<C, WB, DBG>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, tw_g, ktab,
+                              out + 2 * p, status ? status + p : nullptr, lds);
         rt::block_sync();
     }
 }
@@ -761,8 +847,6 @@ SPX_DEVICE void disp5_body(const float* __restrict__ ref, const float* __restric
     typedef Lds<C> L;
     const int tid = rt::thread_id();
     unsigned char* scr = lds + L::SCR_OFF;
-    cf* tw = reinterpret_cast<cf*>(lds + L::TW_OFF);
-    for (int i = tid; i < L::P; i += kThreads) tw[i] = tw_g[i];
     const int64_t stride = (int64_t)ny * nx;
     const NormStats ns = norm_stats(scr, ref, im4, 4, stride, ny, nx, cc_type);
 
@@ -771,15 +855,19 @@ SPX_DEVICE void disp5_body(const float* __restrict__ ref, const float* __restric
     const int NX = 2 * nx, NY = 2 * ny;
     for (int q = 0; q < 4; ++q) {            // order 00, 10, 01, 11 (cc.py:114-117)
         const int ox = q & 1, oy = q >> 1;   // icc[oy::2, ox::2] = cc[::-1, ::-1]
-        stage_pair<C>(lds, ref, im4 + q * stride, ny, nx, ns);
-        rt::block_sync();
-        cc_planes<C>(lds);
-        for (int idx = tid; idx < ny * nx; idx += kThreads) {
-            const int qy = idx / nx, qx = idx % nx;
-            const float val = window_value<C>(lds, ny, nx, qy, qx);
-            const int gi = (2 * qy + oy) * NX + 2 * qx + ox;
-            icc[gi] = val;
-            if (better(val, gi, bv, bi)) { bv = val; bi = gi; }
+        double ssq[2];
+        stage_pair<C>(lds, ref, im4 + q * stride, ny, nx, ns, ssq);
+        const float bal = balance_factor(scr, ssq);
+        const float oscale = 1.0f / ((float)(L::P * L::P) * bal);
+        cc_planes<C>(lds, bal);
+        const int qx = tid & 63;
+        if (qx < nx) {
+            for (int qy = tid >> 6; qy < ny; qy += kThreads / 64) {
+                const float val = window_value<C>(lds, ny, nx, qy, qx, oscale);
+                const int gi = (2 * qy + oy) * NX + 2 * qx + ox;
+                icc[gi] = val;
+                if (better(val, gi, bv, bi)) { bv = val; bi = gi; }
+            }
         }
         rt::block_sync();                    // planes are overwritten by the next stage
     }
@@ -801,6 +889,7 @@ SPX_TKERNEL(256) void disp5_kernel(const float* __restrict__ ref, const float* _
                                    const cf* __restrict__ tw_g, float* __restrict__ icc,
                                    double* __restrict__ out, int* __restrict__ status) {
     SPX_DYN_LDS(lds);
+    load_twiddles<C>(lds, tw_g);
     const int64_t stride = (int64_t)ny * nx;
     for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
         disp5_body<C>(ref + p * stride, im4 + 4 * p * stride, ny, nx, cc_type, tw_g,

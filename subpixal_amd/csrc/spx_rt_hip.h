@@ -13,7 +13,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define SPX_DEVICE __device__ __forceinline__
 #define SPX_KERNEL(nthreads) extern "C" __global__ __launch_bounds__(nthreads)
-#define SPX_TKERNEL(nthreads) __global__ __launch_bounds__(nthreads)
+#define SPX_TKERNEL(nthreads) __global__ __launch_bounds__(nthreads, 2)
 // all LDS lives in ONE dynamic region (cdna guide G17: keep the base 16-B aligned)
 #define SPX_STATIC_LDS(type, name, count) __shared__ type name[count]
 #define SPX_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
@@ -33,6 +33,10 @@ SPX_DEVICE void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// stops the instruction scheduler from moving anything across this point (used to
+// keep independent butterflies from being interleaved into a register-pressure spike)
+SPX_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 SPX_DEVICE float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 SPX_DEVICE int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }

@@ -46,15 +46,25 @@ inline double class_kernel(int c, int P, double t) {
     return s / (double)(P / 2);
 }
 
-// ktab[c][a][m] = K_c( -(a - W/2)/U - (m - 32) ),  c in {0,1}, a in [0,W), m in [0,64)
+// Lane-major operand tables of the MFMA fine-window stage (spx_kernels.h
+// fine_window), W = 16*blocks, lane = 16 lk + lj:
+//   [0][c][blk][lane][s]      = K_c( -(16 blk + lj - W/2)/U - (4 s + lk - 32) )
+//   [1][c][blk][lane][4 t + r] = K_c( -(16 blk + lj - W/2)/U - (16 t + 4 lk + r - 32) )
 inline std::vector<float> make_ktab(int P, int U, int W) {
-    std::vector<float> k(2 * (size_t)W * 64);
-    for (int c = 0; c < 2; ++c)
-        for (int a = 0; a < W; ++a)
-            for (int m = 0; m < 64; ++m) {
-                const double t = -(double)(a - W / 2) / (double)U - (double)(m - 32);
-                k[((size_t)c * W + a) * 64 + m] = (float)class_kernel(c, P, t);
-            }
+    const int blocks = W / 16;
+    std::vector<float> k((size_t)2 * 2 * blocks * 64 * 16);
+    for (int which = 0; which < 2; ++which)
+        for (int c = 0; c < 2; ++c)
+            for (int blk = 0; blk < blocks; ++blk)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 16; ++i) {
+                        const int lk = lane >> 4, lj = lane & 15;
+                        const int m = which == 0 ? (4 * i + lk - 32)
+                                                 : (16 * (i >> 2) + 4 * lk + (i & 3) - 32);
+                        const double t = -(double)(16 * blk + lj - W / 2) / (double)U - (double)m;
+                        k[((((size_t)which * 2 + c) * blocks + blk) * 64 + lane) * 16 + i] =
+                            (float)class_kernel(c, P, t);
+                    }
     return k;
 }
 

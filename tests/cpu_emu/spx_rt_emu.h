@@ -66,6 +66,8 @@ SPX_DEVICE void block_sync() { emu().block_bar->arrive_and_wait(); }
 inline WaveState& my_wave() { return emu().waves[ctx().tid >> 6]; }
 SPX_DEVICE void wave_sync() { my_wave().bar->arrive_and_wait(); }
 
+SPX_DEVICE void sched_fence() {}
+
 SPX_DEVICE float shfl_xor(float v, int m) {
     WaveState& w = my_wave();
     int lane = ctx().tid & 63;
