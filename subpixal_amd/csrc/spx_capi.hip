@@ -164,7 +164,9 @@ int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int
 
 #ifdef SPX_PHASE_TIMING
 // Diagnostic library only (`make diag`): the pair kernel (upsample 10) cut short after
-// phase `phase` (1..13, see tools/phase_timing.py); results are invalid.
+// phase `phase` (1..13, see tools/phase_timing.py); results are invalid.  phase 100 =
+// full kernel with per-phase cycle stamps: out_status must have room for nbatch int32
+// + 20 uint64 (8-byte aligned: nbatch even), zeroed by the caller.
 int spx_diag_pair_phase(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
                         int phase, double* out_dxdy, int32_t* out_status, void* stream) {
     DeviceTables* t = nullptr;
@@ -177,7 +179,7 @@ int spx_diag_pair_phase(const float* ref, const float* img, int64_t nbatch, int 
 #define SPX_PH(k) case k: return launch_pair<1, k>(t, ref, img, nbatch, ny, nx, 10, 0, ktab, out_dxdy, out_status, s);
     switch (phase) {
         SPX_PH(0) SPX_PH(1) SPX_PH(2) SPX_PH(3) SPX_PH(4) SPX_PH(5) SPX_PH(6) SPX_PH(7)
-        SPX_PH(8) SPX_PH(9) SPX_PH(10) SPX_PH(11) SPX_PH(12) SPX_PH(13)
+        SPX_PH(8) SPX_PH(9) SPX_PH(10) SPX_PH(11) SPX_PH(12) SPX_PH(13) SPX_PH(100)
     }
 #undef SPX_PH
     return fail(SPX_E_ARG, "bad phase");

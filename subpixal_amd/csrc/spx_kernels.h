@@ -46,8 +46,43 @@ typedef f32x2 cf;   // complex float: .x = re, .y = im
 
 constexpr int kThreads = 256;
 
+// Work-item id made opaque to the optimiser: values derived from it (LDS addresses,
+// lane masks) are then recomputed in the phase that needs them instead of being
+// hoisted out of the per-pair loop and kept -- i.e. spilled -- for the whole kernel.
+SPX_DEVICE int fresh_tid() { return rt::launder_lane(rt::thread_id()); }
+
 enum { ST_OK = 0, ST_EDGE = 1, ST_NOMAX = 2, ST_OUTSIDE = 3, ST_WINDOW = 4, ST_FEWPTS = 5 };
 enum { CC_PLAIN = 0, CC_NCC = 1, CC_ZNCC = 2 };
+
+// ---------------------------------------------------------------------------
+// Per-phase cycle accounting of the diagnostic build (DBG == 100, `make diag`):
+// every wave stamps the shader clock at phase boundaries and adds its totals to a
+// global array at the end.  With any other DBG the methods compile to nothing.
+// ---------------------------------------------------------------------------
+constexpr int kNumPhases = 20;
+template <int DBG> struct PhaseClock {
+    unsigned long long last;
+    unsigned long long acc[DBG == 100 ? kNumPhases : 1];
+    SPX_DEVICE void start() {
+        if constexpr (DBG == 100) {
+            for (int i = 0; i < kNumPhases; ++i) acc[i] = 0;
+            last = rt::clock_stamp();
+        }
+    }
+    SPX_DEVICE void tick(int phase) {
+        if constexpr (DBG == 100) {
+            const unsigned long long now = rt::clock_stamp();
+            acc[phase] += now - last;
+            last = now;
+        }
+    }
+    SPX_DEVICE void flush(unsigned long long* out) {
+        if constexpr (DBG == 100) {
+            if ((rt::thread_id() & 63) == 0)
+                for (int i = 0; i < kNumPhases; ++i) rt::atomic_add_u64(out + i, acc[i]);
+        }
+    }
+};
 
 // ---------------------------------------------------------------------------
 // complex helpers
@@ -133,12 +168,16 @@ template <int C> struct Lds {
     static constexpr int ZBUF_BYTES = 2 * 64 * ZS * 4;
     static constexpr int XCH_WAVE_BYTES = 64 * XS * 4;
     static constexpr int XCH_BYTES = NCLS * XCH_WAVE_BYTES;
-    static constexpr int PLANE_BYTES = 64 * PS * 4;
-    static constexpr int PLANES_BYTES = NCLS * PLANE_BYTES;
+    // class plane c occupies the head of wave c's OWN exchange buffer, so no other
+    // wave's exchange traffic can touch it (no barrier needed before writing it)
+    static constexpr int PLANE_STRIDE_BYTES = XCH_WAVE_BYTES;
+    static constexpr int FB_OFF = R_OFF + XCH_BYTES;        // fine windows
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
-    // fine window of W x W floats sits behind the planes
+    // fine window(s) of W x W floats sit behind the exchange region: one per class for
+    // W <= 32 (summed by the reader, one barrier), a single shared one above that
+    static constexpr int fb_count(int W) { return W <= 32 ? NCLS : 1; }
     static constexpr int total(int W) {
-        return R_OFF + cmax(cmax(ZBUF_BYTES, XCH_BYTES), PLANES_BYTES + W * W * 4);
+        return cmax(R_OFF + cmax(ZBUF_BYTES, XCH_BYTES), FB_OFF + fb_count(W) * W * W * 4);
     }
 };
 
@@ -170,14 +209,30 @@ template <int NV> SPX_DEVICE void block_sum(unsigned char* lds_scr, double (&v)[
 #pragma unroll
         for (int i = 0; i < NV; ++i) part[(tid >> 6) * 4 + i] = v[i];
     }
-    rt::block_sync();
+    rt::block_sync_lds();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         double s = 0.0;
         for (int w = 0; w < kThreads / 64; ++w) s += part[w * 4 + i];
         v[i] = s;
     }
-    rt::block_sync();
+    rt::block_sync_lds();
+}
+
+// float version for quantities that only steer scaling (sum of squares): one barrier.
+// The scratch slots are next written after at least one more workgroup barrier.
+SPX_DEVICE void block_sum2f(unsigned char* lds_scr, float& a, float& b) {
+    const int tid = rt::thread_id();
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        a += rt::shfl_xor(a, m);
+        b += rt::shfl_xor(b, m);
+    }
+    float* part = reinterpret_cast<float*>(lds_scr + SCR_STAT);
+    if ((tid & 63) == 0) { part[2 * (tid >> 6)] = a; part[2 * (tid >> 6) + 1] = b; }
+    rt::block_sync_lds();
+    a = (part[0] + part[2]) + (part[4] + part[6]);
+    b = (part[1] + part[3]) + (part[5] + part[7]);
 }
 
 // (value, index) arg-max with centroid.py:114's tie rule: the FIRST maximum in
@@ -185,7 +240,7 @@ template <int NV> SPX_DEVICE void block_sum(unsigned char* lds_scr, double (&v)[
 SPX_DEVICE bool better(float v, int i, float bv, int bi) {
     return (v > bv) || (v == bv && i < bi);
 }
-SPX_DEVICE void block_argmax(unsigned char* lds_scr, float& v, int& idx) {
+SPX_DEVICE void block_argmax(unsigned char* lds_scr, float& v, int& idx, int slot = 0) {
     const int tid = rt::thread_id();
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -196,12 +251,13 @@ SPX_DEVICE void block_argmax(unsigned char* lds_scr, float& v, int& idx) {
     float* rf = reinterpret_cast<float*>(lds_scr + SCR_RED_F);
     int* ri = reinterpret_cast<int*>(lds_scr + SCR_RED_I);
     if ((tid & 63) == 0) { rf[tid >> 6] = v; ri[tid >> 6] = idx; }
-    rt::block_sync();
+    rt::block_sync_lds();
     v = rf[0];
     idx = ri[0];
     for (int w = 1; w < kThreads / 64; ++w)
         if (better(rf[w], ri[w], v, idx)) { v = rf[w]; idx = ri[w]; }
-    rt::block_sync();
+    rt::block_sync_lds();
+    (void)slot;
 }
 
 // ---------------------------------------------------------------------------
@@ -263,7 +319,18 @@ template <int C> SPX_DEVICE void load_twiddles(unsigned char* lds, const cf* __r
     typedef Lds<C> L;
     cf* tw = reinterpret_cast<cf*>(lds + L::TW_OFF);
     for (int i = rt::thread_id(); i < L::P; i += kThreads) tw[i] = tw_g[i];
-    rt::block_sync();
+    rt::block_sync_lds();
+}
+
+// L2 warm-up of the NEXT pair, issued when the current pair enters its arg-max /
+// refine / fit tail: one dword per 128-byte line (256 threads x 128 B = the 32 KiB of a
+// full 64x64 pair).  The value is only kept alive until the next staging, where the
+// real 16-byte loads then hit L2 instead of HBM.  (Holding the whole next pair in
+// registers does not work: the kernel is at its VGPR budget and they would spill.)
+SPX_DEVICE float warm_next_pair(const float* __restrict__ ref, const float* __restrict__ img) {
+    const int tid = rt::thread_id();
+    const float* p = (tid < 128) ? ref + tid * 32 : img + (tid - 128) * 32;
+    return *p;
 }
 
 // ---------------------------------------------------------------------------
@@ -280,10 +347,10 @@ struct NormStats {      // what _normalize applies: im = (im - mean)/std on im !
 template <int C>
 SPX_DEVICE void stage_pair(unsigned char* lds, const float* __restrict__ ref,
                            const float* __restrict__ img, int ny, int nx,
-                           const NormStats& ns, double (&ssq)[2]) {
+                           const NormStats& ns, float (&ssq)[2]) {
     typedef Lds<C> L;
     float sr = 0.0f, sm = 0.0f;
-    const int tid = rt::thread_id();
+    const int tid = fresh_tid();
     float* zre = reinterpret_cast<float*>(lds + L::R_OFF);
     float* zim = zre + 64 * L::ZS;
     const bool aligned = ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(img)) & 15) == 0;
@@ -312,8 +379,8 @@ SPX_DEVICE void stage_pair(unsigned char* lds, const float* __restrict__ ref,
 #pragma unroll
             for (int e = 0; e < 4; ++e) { sr += r[e] * r[e]; sm += m[e] * m[e]; }
         }
-        ssq[0] = (double)sr;
-        ssq[1] = (double)sm;
+        ssq[0] = sr;
+        ssq[1] = sm;
         return;
     }
     for (int idx = tid; idx < 64 * 64; idx += kThreads) {
@@ -336,18 +403,18 @@ SPX_DEVICE void stage_pair(unsigned char* lds, const float* __restrict__ ref,
         sr += r * r;
         sm += m * m;
     }
-    ssq[0] = (double)sr;
-    ssq[1] = (double)sm;
+    ssq[0] = sr;
+    ssq[1] = sm;
 }
 
 // Z = FFT(ref + i*bal*flip(img)) is squared, so the cross term 2 ref*img is rounded
 // relative to ref*ref + img*img: keep the two images at comparable amplitude.  `bal`
 // is an exact power of two near sqrt(sum ref^2 / sum img^2) (1 when either is zero);
-// results are multiplied by 1/bal, also exact.  Workgroup-wide; two barriers.
-SPX_DEVICE float balance_factor(unsigned char* lds_scr, double (&ssq)[2]) {
-    block_sum<2>(lds_scr, ssq);
-    if (!(ssq[0] > 0.0) || !(ssq[1] > 0.0)) return 1.0f;
-    const float ratio = (float)sqrt(ssq[0] / ssq[1]);
+// results are multiplied by 1/bal, also exact.  Workgroup-wide; one barrier.
+SPX_DEVICE float balance_factor(unsigned char* lds_scr, float (&ssq)[2]) {
+    block_sum2f(lds_scr, ssq[0], ssq[1]);
+    if (!(ssq[0] > 0.0f) || !(ssq[1] > 0.0f)) return 1.0f;
+    const float ratio = __builtin_sqrtf(ssq[0] / ssq[1]);
     if (!(ratio > 1e-30f && ratio < 1e30f)) return 1.0f;
     // largest power of two <= ratio: keep the exponent field, clear the mantissa
     return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, ratio) & 0x7f800000u);
@@ -375,10 +442,11 @@ SPX_DEVICE float fold_tile(cf (&v)[8][8]) {
 // cc_planes: staged input planes -> the NCLS real class planes d_c in LDS.
 // Caller must have issued a block_sync after staging; ends with a block_sync.
 // ---------------------------------------------------------------------------
-template <int C, int DBG = 0> SPX_DEVICE bool cc_planes(unsigned char* lds, float bal) {
+template <int C, int DBG = 0>
+SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk) {
     typedef Lds<C> L;
     static_assert(C == 2, "class decomposition implemented for P = 128");
-    const int tid = rt::thread_id();
+    const int tid = fresh_tid();
     const int wave = tid >> 6, lane = tid & 63;
     const int cy = wave / C, cx = wave % C;       // this wave's parity class
     const int l1 = lane >> 3, l0 = lane & 7;      // lane digits (y-ish, x-ish)
@@ -397,7 +465,8 @@ template <int C, int DBG = 0> SPX_DEVICE bool cc_planes(unsigned char* lds, floa
             const int a = (l1 + 8 * y1) * L::ZS + l0 + 8 * x1;
             v[y1][x1] = cf{zre[a], bal * zim[a]};
         }
-    rt::block_sync();                       // all waves have read the staged input
+    rt::block_sync_lds();                       // all waves have read the staged input
+    clk.tick(1);
 
     // class pre-twiddle w_P^{c (8 y1)} (the free radix-2 stage of the zero pad)
     if (cy) {
@@ -419,6 +488,7 @@ template <int C, int DBG = 0> SPX_DEVICE bool cc_planes(unsigned char* lds, floa
     fft8_y<1>(v);                           // y1 -> kyb
     fft8_x<1>(v);                           // x1 -> kxb
     SPX_DBG_STOP(2);
+    clk.tick(2);
     // twiddle w_P^{y0 (cy + C kyb)} w_P^{x0 (cx + C kxb)}
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
@@ -434,6 +504,7 @@ template <int C, int DBG = 0> SPX_DEVICE bool cc_planes(unsigned char* lds, floa
     }
 
     SPX_DBG_STOP(3);
+    clk.tick(3);
     // ---- transposition: (lane (y0,x0), reg (kyb,kxb)) -> (lane (kyb,kxb), reg (y0,x0))
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
@@ -450,10 +521,12 @@ template <int C, int DBG = 0> SPX_DEVICE bool cc_planes(unsigned char* lds, floa
     }
 
     SPX_DBG_STOP(4);
+    clk.tick(4);
     // ---- forward round B: lane = (kyb, kxb), registers (y0, x0) -> (kya, kxa)
     fft8_y<1>(v);
     fft8_x<1>(v);
     SPX_DBG_STOP(5);
+    clk.tick(5);
     // now v[kya][kxa] = Z[ky][kx], ky = cy + C*l1 + 8C*kya, kx = cx + C*l0 + 8C*kxa
 
     // ---- spectral product: W = Z^2 (see the header: Im IFFT(Z^2) = 2 ref*flip(img))
@@ -466,6 +539,7 @@ template <int C, int DBG = 0> SPX_DEVICE bool cc_planes(unsigned char* lds, floa
         }
 
     SPX_DBG_STOP(6);
+    clk.tick(6);
     // ---- inverse round A': registers (kya, kxa) -> (y0, x0), lane = (kyb, kxb)
     fft8_y<-1>(v);
     fft8_x<-1>(v);
@@ -482,6 +556,7 @@ template <int C, int DBG = 0> SPX_DEVICE bool cc_planes(unsigned char* lds, floa
         for (int j = 0; j < 8; ++j) v[j][x0] = cmulc(v[j][x0], wx);
     }
     SPX_DBG_STOP(7);
+    clk.tick(7);
     // ---- transposition back: -> lane (y0, x0), registers (kyb, kxb)
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
@@ -497,13 +572,15 @@ template <int C, int DBG = 0> SPX_DEVICE bool cc_planes(unsigned char* lds, floa
         rt::wave_sync();
     }
     SPX_DBG_STOP(8);
+    clk.tick(8);
     // ---- inverse round B': registers (kyb, kxb) -> (y1, x1)
     fft8_y<-1>(v);
     fft8_x<-1>(v);
     SPX_DBG_STOP(9);
-    // class post-twiddle conj(w_P^{8 (cy y1 + cx x1)}); half the imaginary part is kept
-    rt::block_sync();      // every wave is done with its transposition buffer
-    float* plane = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::PLANE_BYTES);
+    clk.tick(9);
+    // class post-twiddle conj(w_P^{8 (cy y1 + cx x1)}); half the imaginary part is kept.
+    // The plane goes into this wave's own exchange buffer (its reads above are done).
+    float* plane = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::PLANE_STRIDE_BYTES);
 #pragma unroll
     for (int y1 = 0; y1 < 8; ++y1) {
         const cf wy = tw[8 * cy * y1];
@@ -515,7 +592,8 @@ template <int C, int DBG = 0> SPX_DEVICE bool cc_planes(unsigned char* lds, floa
             plane[(l1 + 8 * y1) * L::PS + l0 + 8 * x1] = 0.5f * (a.y * w.x - a.x * w.y);  // Im(a conj w)/2
         }
     }
-    rt::block_sync();
+    rt::block_sync_lds();
+    clk.tick(10);
     return false;
 }
 
@@ -536,7 +614,7 @@ SPX_DEVICE float window_value(const unsigned char* lds, int ny, int nx, int qy, 
     float acc = 0.0f;
 #pragma unroll
     for (int c = 0; c < C * C; ++c) {
-        const float d = planes[c * (64 * L::PS) + my * L::PS + mx];
+        const float d = planes[c * (L::PLANE_STRIDE_BYTES / 4) + my * L::PS + mx];
         const int neg = ((c / C) & sy) ^ ((c % C) & sx);
         acc += neg ? -d : d;
     }
@@ -607,9 +685,9 @@ SPX_DEVICE PeakResult peak_from_argmax(unsigned char* lds_scr, int imax, int jma
     if (y1 < 0) y1 = 0;
     double* fit = reinterpret_cast<double*>(lds_scr + SCR_FIT);
     if (tid < 25) fit[tid] = (double)val(x1 + tid % 5, y1 + tid / 5);
-    rt::block_sync();
+    rt::block_sync_lds();
     if (tid == 0) r = quad_fit_5x5(fit, x1, y1, imax, jmax, NX, NY);
-    rt::block_sync();
+    rt::block_sync_lds();
     return r;
 }
 
@@ -633,14 +711,15 @@ SPX_DEVICE void fine_window(unsigned char* lds, const float* __restrict__ ktab,
     typedef Lds<C> L;
     static_assert(C == 2, "");
     constexpr int W = 16 * WB;
-    const int tid = rt::thread_id();
+    const int tid = fresh_tid();
     const int wave = tid >> 6, lane = tid & 63;
     const int cy = wave / C, cx = wave % C;
     const int lk = lane >> 4, lj = lane & 15;
-    const float* plane = reinterpret_cast<const float*>(lds + L::R_OFF + wave * L::PLANE_BYTES);
-    float* fbuf = reinterpret_cast<float*>(lds + L::R_OFF + L::PLANES_BYTES);
+    const float* plane = reinterpret_cast<const float*>(lds + L::R_OFF + wave * L::PLANE_STRIDE_BYTES);
+    float* fbuf = reinterpret_cast<float*>(lds + L::FB_OFF);
     const int lyc = conv_index(ny, qyc), lxc = conv_index(nx, qxc);
     // table slices of this lane: [2 (y|x)][2 (class)][WB][64 lanes][16]
+    ktab = rt::launder(ktab);
     const f32x4* kty = reinterpret_cast<const f32x4*>(ktab) + ((size_t)(0 * 2 + cy) * WB * 64 + lane) * 4;
     const f32x4* ktx = reinterpret_cast<const f32x4*>(ktab) + ((size_t)(1 * 2 + cx) * WB * 64 + lane) * 4;
 
@@ -699,23 +778,121 @@ SPX_DEVICE void fine_window(unsigned char* lds, const float* __restrict__ ktab,
                     f[bb][ab] = rt::mfma_16x16x4(sgn * ka[bb][r], acc[ab][t][r], f[bb][ab]);
         }
     }
-    // sum the 4 classes in fixed order through LDS
     const float scale = 1.0f / (float)(L::P * L::P);
-    for (int c = 0; c < C * C; ++c) {
-        if (wave == c) {
+    if constexpr (L::fb_count(W) == C * C) {
+        // one window per class; the reader adds the four in fixed order (fine_value)
+        float* mine = fbuf + wave * W * W;
 #pragma unroll
-            for (int bb = 0; bb < WB; ++bb)
+        for (int bb = 0; bb < WB; ++bb)
 #pragma unroll
-                for (int ab = 0; ab < WB; ++ab)
+            for (int ab = 0; ab < WB; ++ab)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int b = bb * 16 + 4 * lk + r, a = ab * 16 + lj;
-                        const float val = f[bb][ab][r] * scale;
-                        if (c == 0) fbuf[b * W + a] = val; else fbuf[b * W + a] += val;
-                    }
+                for (int r = 0; r < 4; ++r)
+                    mine[(bb * 16 + 4 * lk + r) * W + ab * 16 + lj] = f[bb][ab][r] * scale;
+        rt::block_sync_lds();
+    } else {
+        // large windows: accumulate the 4 classes in fixed order into one buffer
+        for (int c = 0; c < C * C; ++c) {
+            if (wave == c) {
+#pragma unroll
+                for (int bb = 0; bb < WB; ++bb)
+#pragma unroll
+                    for (int ab = 0; ab < WB; ++ab)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int b = bb * 16 + 4 * lk + r, a = ab * 16 + lj;
+                            const float val = f[bb][ab][r] * scale;
+                            if (c == 0) fbuf[b * W + a] = val; else fbuf[b * W + a] += val;
+                        }
+            }
+            rt::block_sync_lds();
         }
-        rt::block_sync();
     }
+}
+
+// value of the fine window at (x offset index b, y offset index a)
+template <int C, int W>
+SPX_DEVICE float fine_value(const unsigned char* lds, int b, int a) {
+    typedef Lds<C> L;
+    const float* fbuf = reinterpret_cast<const float*>(lds + L::FB_OFF);
+    if constexpr (L::fb_count(W) == C * C) {
+        float acc = fbuf[b * W + a];
+#pragma unroll
+        for (int c = 1; c < C * C; ++c) acc += fbuf[c * W * W + b * W + a];
+        return acc;
+    } else {
+        return fbuf[b * W + a];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Coarse arg-max over the flipped 'same' window, walking the class planes in
+// storage order with 16-byte LDS reads.  A plane element (my, mx) is convolution
+// index l = m or m + 64, whichever lies in the window [lo, lo + n), lo = (n-1)/2;
+// its flipped window index is q = (n-1) + lo - l (see conv_index).
+// ---------------------------------------------------------------------------
+template <int C>
+SPX_DEVICE void coarse_argmax(const unsigned char* lds, int ny, int nx, float out_scale,
+                              float& bv, int& bi) {
+    typedef Lds<C> L;
+    const int tid = fresh_tid();
+    const int loy = (ny - 1) / 2, lox = (nx - 1) / 2;
+    bv = -__builtin_inff();
+    bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = tid + i * kThreads;          // 1024 float4 chunks per plane
+        const int my = g >> 4, mx4 = (g & 15) << 2;
+        const int ly = my + (my < loy ? 64 : 0);
+        const int qy = (ny - 1) + loy - ly;
+        const int sy = ly >> 6;
+        f32x4 d[C * C];
+#pragma unroll
+        for (int c = 0; c < C * C; ++c)
+            d[c] = *reinterpret_cast<const f32x4*>(lds + L::R_OFF + c * L::PLANE_STRIDE_BYTES +
+                                                   (my * L::PS + mx4) * 4);
+        if (qy < 0) continue;                      // row outside the window
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int mx = mx4 + e;
+            const int lx = mx + (mx < lox ? 64 : 0);
+            const int qx = (nx - 1) + lox - lx;
+            const int sx = lx >> 6;
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < C * C; ++c) {
+                const int neg = ((c / C) & sy) ^ ((c % C) & sx);
+                acc += neg ? -d[c][e] : d[c][e];
+            }
+            const float val = acc * out_scale;
+            const int idx = qy * nx + qx;
+            if (qx >= 0 && better(val, idx, bv, bi)) { bv = val; bi = idx; }
+        }
+    }
+}
+
+// 5x5 fit by wave 0 alone (no workgroup barrier): lanes 0..24 fetch the box values,
+// lanes 0..5 each form one of the six moment sums, lane 0 finishes (quad_fit_5x5's
+// arithmetic, same order of operations per sum).  Other waves return at once; the
+// caller's end-of-pair barrier protects the LDS scratch.
+template <typename ValFn>
+SPX_DEVICE PeakResult peak_fit_wave0(unsigned char* lds_scr, int imax, int jmax, int NX, int NY,
+                                     ValFn val) {
+    const int tid = rt::thread_id();
+    PeakResult r;
+    r.x = (double)imax; r.y = (double)jmax; r.status = ST_EDGE;
+    if (imax == 0 || jmax == 0) return r;              // centroid.py:171-172
+    if (tid >= 64) return r;
+    int x1 = imax - 2, y1 = jmax - 2;                  // centroid.py:165-184
+    if (x1 > NX - 5) x1 = NX - 5;
+    if (y1 > NY - 5) y1 = NY - 5;
+    if (x1 < 0) x1 = 0;
+    if (y1 < 0) y1 = 0;
+    double* fit = reinterpret_cast<double*>(lds_scr + SCR_FIT);
+    if (tid < 25) fit[tid] = (double)val(x1 + tid % 5, y1 + tid / 5);
+    rt::wave_sync();
+    if (tid == 0) r = quad_fit_5x5(fit, x1, y1, imax, jmax, NX, NY);
+    return r;
 }
 
 // ---------------------------------------------------------------------------
@@ -726,50 +903,51 @@ template <int C, int WB, int DBG = 0>
 SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict__ img,
                           int ny, int nx, int U, int cc_type, const cf* __restrict__ tw_g,
                           const float* __restrict__ ktab, double* __restrict__ out,
-                          int* __restrict__ status, unsigned char* lds) {
+                          int* __restrict__ status, unsigned char* lds, PhaseClock<DBG>& clk,
+                          const float* __restrict__ next_ref, const float* __restrict__ next_img,
+                          float& warm) {
     typedef Lds<C> L;
-    const int tid = rt::thread_id();
+    ny = rt::launder_uniform(ny);
+    nx = rt::launder_uniform(nx);
+    U = rt::launder_uniform(U);
+    const int tid = fresh_tid();
     unsigned char* scr = lds + L::SCR_OFF;
     const NormStats ns = norm_stats(scr, ref, img, 1, 0, ny, nx, cc_type);
-    double ssq[2];
+    float ssq[2];
+    rt::consume(warm);        // the warm-up load of this pair has landed (or was never issued)
     stage_pair<C>(lds, ref, img, ny, nx, ns, ssq);
     const float bal = balance_factor(scr, ssq);       // includes the barrier after staging
     const float oscale = 1.0f / ((float)(L::P * L::P) * bal);
+    clk.tick(0);
     if constexpr (DBG == 1) return;
-    if (cc_planes<C, DBG>(lds, bal)) return;
+    if (cc_planes<C, DBG>(lds, bal, clk)) return;
     if constexpr (DBG == 10) return;
+    // pull the next pair into L2 while this one is in its tail
+    if (next_ref) warm = warm_next_pair(next_ref, next_img);
 
     // coarse arg-max over the flipped 'same' window (centroid.py:114-116)
-    float bv = -__builtin_inff();
-    int bi = 0x7fffffff;
-    {
-        const int qx = tid & 63;             // nx <= 64: one column per lane
-        if (qx < nx) {
-            for (int qy = tid >> 6; qy < ny; qy += kThreads / 64) {
-                const float val = window_value<C>(lds, ny, nx, qy, qx, oscale);
-                const int idx = qy * nx + qx;
-                if (better(val, idx, bv, bi)) { bv = val; bi = idx; }
-            }
-        }
-    }
+    float bv;
+    int bi;
+    coarse_argmax<C>(lds, ny, nx, oscale, bv, bi);
     block_argmax(scr, bv, bi);
     int qyc = bi / nx, qxc = bi - (bi / nx) * nx;
+    clk.tick(11);
     if constexpr (DBG == 11) { if (tid == 0) out[0] = (double)bi; return; }
 
     PeakResult pk;
     if constexpr (WB == 0) {
-        pk = peak_from_argmax(scr, qxc, qyc, nx, ny, [&](int x, int y) {
+        pk = peak_fit_wave0(scr, qxc, qyc, nx, ny, [&](int x, int y) {
             return window_value<C>(lds, ny, nx, y, x, oscale);
         });
     } else {
         constexpr int W = 16 * (WB > 0 ? WB : 1);
         const int NX = U * nx, NY = U * ny;
-        const float* fbuf = reinterpret_cast<const float*>(lds + L::R_OFF + L::PLANES_BYTES);
         int imax = 0, jmax = 0;
         bool inside = false;
         for (int iter = 0; iter < 4; ++iter) {
             fine_window<C, (WB > 0 ? WB : 1)>(lds, ktab, ny, nx, qyc, qxc);
-            if constexpr (DBG == 12) { if (tid == 0) out[0] = (double)fbuf[0]; return; }
+            clk.tick(12);
+            if constexpr (DBG == 12) { if (tid == 0) out[0] = (double)fine_value<C, W>(lds, 0, 0); return; }
             // arg-max over the part of the window inside the virtual image
             const int fx0 = U * qxc - W / 2, fy0 = U * qyc - W / 2;
             float fv = -__builtin_inff();
@@ -778,11 +956,12 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
                 const int a = idx / W, b = idx % W;       // a: y offset, b: x offset
                 const int gy = fy0 + a, gx = fx0 + b;
                 if (gy >= 0 && gy < NY && gx >= 0 && gx < NX) {
-                    const float val = fbuf[b * W + a];
+                    const float val = fine_value<C, W>(lds, b, a);
                     if (better(val, idx, fv, fi)) { fv = val; fi = idx; }
                 }
             }
             block_argmax(scr, fv, fi);
+            clk.tick(13);
             if constexpr (DBG == 13) { if (tid == 0) out[0] = (double)fi; return; }
             const int a = fi / W, b = fi % W;
             jmax = fy0 + a;
@@ -804,8 +983,8 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
         }
         if (inside) {
             const int fx0 = U * qxc - W / 2, fy0 = U * qyc - W / 2;
-            pk = peak_from_argmax(scr, imax, jmax, NX, NY, [&](int x, int y) {
-                return fbuf[(x - fx0) * W + (y - fy0)];
+            pk = peak_fit_wave0(scr, imax, jmax, NX, NY, [&](int x, int y) {
+                return fine_value<C, W>(lds, x - fx0, y - fy0);
             });
         } else {
             pk.x = (double)imax; pk.y = (double)jmax; pk.status = ST_WINDOW;
@@ -817,6 +996,7 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
         out[1] = pk.y / (double)U - (double)((ny - 1) / 2);
         if (status) status[0] = pk.status;
     }
+    clk.tick(14);
 }
 
 template <int C, int WB, int DBG = 0>
@@ -826,12 +1006,24 @@ SPX_TKERNEL(256) void pair_kernel(const float* __restrict__ ref, const float* __
                                   double* __restrict__ out, int* __restrict__ status) {
     SPX_DYN_LDS(lds);
     load_twiddles<C>(lds, tw_g);
+    PhaseClock<DBG> clk;
+    clk.start();
     const int64_t stride = (int64_t)ny * nx;
-    for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
+    const bool full = ny == 64 && nx == 64;
+    const int64_t step = rt::grid_size();
+    float warm = 0.0f;
+    for (int64_t p = rt::block_id(); p < nbatch; p += step) {
+        const bool more = full && (p + step < nbatch);
         pair_body<C, WB, DBG>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, tw_g, ktab,
-                              out + 2 * p, status ? status + p : nullptr, lds);
-        rt::block_sync();
+                              out + 2 * p, status ? status + p : nullptr, lds, clk,
+                              more ? ref + (p + step) * stride : nullptr,
+                              more ? img + (p + step) * stride : nullptr, warm);
+        rt::block_sync_lds();
+        clk.tick(15);
     }
+    // diagnostic build: the per-phase cycle totals go to the tail of the status array
+    if constexpr (DBG == 100)
+        clk.flush(reinterpret_cast<unsigned long long*>(status + nbatch));
 }
 
 // ---------------------------------------------------------------------------
@@ -855,11 +1047,12 @@ SPX_DEVICE void disp5_body(const float* __restrict__ ref, const float* __restric
     const int NX = 2 * nx, NY = 2 * ny;
     for (int q = 0; q < 4; ++q) {            // order 00, 10, 01, 11 (cc.py:114-117)
         const int ox = q & 1, oy = q >> 1;   // icc[oy::2, ox::2] = cc[::-1, ::-1]
-        double ssq[2];
+        float ssq[2];
         stage_pair<C>(lds, ref, im4 + q * stride, ny, nx, ns, ssq);
         const float bal = balance_factor(scr, ssq);
         const float oscale = 1.0f / ((float)(L::P * L::P) * bal);
-        cc_planes<C>(lds, bal);
+        PhaseClock<0> noclk;
+        cc_planes<C>(lds, bal, noclk);
         const int qx = tid & 63;
         if (qx < nx) {
             for (int qy = tid >> 6; qy < ny; qy += kThreads / 64) {
@@ -869,8 +1062,9 @@ SPX_DEVICE void disp5_body(const float* __restrict__ ref, const float* __restric
                 if (better(val, gi, bv, bi)) { bv = val; bi = gi; }
             }
         }
-        rt::block_sync();                    // planes are overwritten by the next stage
+        rt::block_sync_lds();                    // planes are overwritten by the next stage
     }
+    rt::block_sync();        // icc (GLOBAL memory) written above is read below by other waves
     block_argmax(scr, bv, bi);
     const int jmax = bi / NX, imax = bi % NX;
     PeakResult pk = peak_from_argmax(scr, imax, jmax, NX, NY, [&](int x, int y) {
@@ -894,7 +1088,7 @@ SPX_TKERNEL(256) void disp5_kernel(const float* __restrict__ ref, const float* _
     for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
         disp5_body<C>(ref + p * stride, im4 + 4 * p * stride, ny, nx, cc_type, tw_g,
                       icc + 4 * p * stride, out + 2 * p, status ? status + p : nullptr, lds);
-        rt::block_sync();
+        rt::block_sync_lds();
     }
 }
 

@@ -25,6 +25,16 @@ SPX_DEVICE int64_t grid_size() { return (int64_t)gridDim.x; }
 // workgroup barrier (LDS + global visibility at workgroup scope)
 SPX_DEVICE void block_sync() { __syncthreads(); }
 
+// Workgroup barrier that orders LDS traffic only: global loads/stores issued before it
+// (prefetches, result stores) stay in flight across it (no vmcnt(0) drain, unlike
+// __syncthreads()).  Use block_sync() where another wave reads GLOBAL data written
+// before the barrier.
+SPX_DEVICE void block_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Ordering point between LDS accesses of the lanes of ONE wave (per-wave LDS
 // regions).  A wave's DS instructions execute in issue order, so only the
 // compiler has to be stopped from reordering across this point.
@@ -33,6 +43,37 @@ SPX_DEVICE void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// Makes a (wave-uniform) pointer opaque to the optimiser at this point, so loads
+// through it are not hoisted out of the per-pair loop into long-lived registers.
+template <typename T> SPX_DEVICE T* launder(T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+SPX_DEVICE int launder_uniform(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+// Same for a per-lane value: address arithmetic derived from it is redone where it
+// is needed instead of being kept in registers across the whole per-pair loop.
+SPX_DEVICE int launder_lane(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// shader-clock stamp for the diagnostic build (cdna guide section 7, in-kernel stamps)
+SPX_DEVICE unsigned long long clock_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+SPX_DEVICE void atomic_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
+
+// forces `v` to be materialised here (and nothing else)
+SPX_DEVICE void consume(float v) { asm volatile("" ::"v"(v)); }
 
 // stops the instruction scheduler from moving anything across this point (used to
 // keep independent butterflies from being interleaved into a register-pressure spike)

@@ -12,6 +12,9 @@ extern "C" int emu_lds_bytes(int U) {
     return Lds<2>::total(wb > 0 ? 16 * wb : 0);
 }
 
+static int64_t g_grid = 0;     // 0: one workgroup per item; else grid-stride over the batch
+extern "C" void emu_set_grid(int64_t g) { g_grid = g; }
+
 extern "C" int emu_pair(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
                         int U, int cc_type, double* out, int* status) {
     if (ny < 5 || nx < 5 || ny > 64 || nx > 64) return -1;
@@ -22,7 +25,7 @@ extern "C" int emu_pair(const float* ref, const float* img, int64_t nbatch, int 
     if (wb > 0) kt = host::make_ktab(128, U, 16 * wb);
     const cf* twp = reinterpret_cast<const cf*>(tw.data());
     const float* ktp = kt.empty() ? nullptr : kt.data();
-    auto run = [&](auto fn) { rt::launch(nbatch, kThreads, fn); };
+    auto run = [&](auto fn) { rt::launch(g_grid > 0 && g_grid < nbatch ? g_grid : nbatch, kThreads, fn); };
     switch (wb) {
     case 0: run([&] { pair_kernel<2, 0>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
     case 1: run([&] { pair_kernel<2, 1>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;

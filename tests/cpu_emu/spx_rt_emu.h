@@ -62,10 +62,17 @@ SPX_DEVICE int thread_id() { return ctx().tid; }
 SPX_DEVICE int64_t block_id() { return ctx().bid; }
 SPX_DEVICE int64_t grid_size() { return emu().nblocks; }
 SPX_DEVICE void block_sync() { emu().block_bar->arrive_and_wait(); }
+SPX_DEVICE void block_sync_lds() { emu().block_bar->arrive_and_wait(); }
 
 inline WaveState& my_wave() { return emu().waves[ctx().tid >> 6]; }
 SPX_DEVICE void wave_sync() { my_wave().bar->arrive_and_wait(); }
 
+template <typename T> SPX_DEVICE T* launder(T* p) { return p; }
+SPX_DEVICE int launder_lane(int v) { return v; }
+SPX_DEVICE int launder_uniform(int v) { return v; }
+SPX_DEVICE unsigned long long clock_stamp() { return 0; }
+SPX_DEVICE void atomic_add_u64(unsigned long long* p, unsigned long long v) { (void)p; (void)v; }
+SPX_DEVICE void consume(float v) { (void)v; }
 SPX_DEVICE void sched_fence() {}
 
 SPX_DEVICE float shfl_xor(float v, int m) {

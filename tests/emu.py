@@ -31,6 +31,10 @@ def _p(a, t):
     return None if a is None else a.ctypes.data_as(t)
 
 
+def set_grid(g):
+    lib().emu_set_grid(ctypes.c_int64(g))
+
+
 def pair(ref, img, upsample=1, cc=0):
     ref = np.ascontiguousarray(ref, np.float32)
     img = np.ascontiguousarray(img, np.float32)

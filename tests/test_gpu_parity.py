@@ -303,7 +303,7 @@ def test_full_size_properties(spx):
     d5 = spx.xcorr_refine_batch(ref[:20000] * 1024.0, img[:20000] * 0.03125, upsample=10)
     assert torch.equal(d5, d1[:20000])
     d6 = spx.xcorr_refine_batch(ref[:20000] * 1000.0, img[:20000] * 0.001, upsample=10)
-    assert float((d6 - d1[:20000]).abs().max()) < 5e-5
+    assert float((d6 - d1[:20000]).abs().max()) < 2e-4     # inputs re-rounded by the non-pow2 scaling
     assert float((d6 - truth[:20000]).abs().max()) < 1e-3
     # (5) oracle on a bounded sample of the same device-generated inputs
     k = 24

@@ -22,6 +22,19 @@ def test_pair_mode_vs_oracle():
         assert np.array_equal(st, est)
 
 
+def test_pair_mode_grid_stride_pipeline():
+    """fewer workgroups than pairs: exercises the one-pair-ahead register prefetch"""
+    ref, img, truth = datagen.pair_batch(4, 5, 64)
+    emu.set_grid(2)
+    try:
+        got, st = emu.pair(ref, img, 10)
+    finally:
+        emu.set_grid(0)
+    exp, est = orc.xcorr_refine_batch(ref, img, 10)
+    assert np.max(np.abs(got - exp)) < 1e-4
+    assert np.array_equal(st, est)
+
+
 def test_pair_mode_shapes_and_cc_types():
     rng = np.random.default_rng(1)
     for (ny, nx) in ((20, 31), (64, 40), (5, 6)):

@@ -11,4 +11,4 @@ for p in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us', '/sys
 os.system('lscpu | head -20')
 os.system('nproc')
 PY
-timeout -k 10 600 python tools/phase_timing.py 2>&1 | tee gpurun_out/phase_timing.log
+timeout -k 10 600 python tools/phase_cycles.py 2>&1 | tee gpurun_out/phase_cycles.log
