@@ -49,9 +49,26 @@ def _cpu_worker(args):
     return count, time.perf_counter() - t0
 
 
-def cpu_baseline(per_core=600):
+def usable_cores():
+    """Host threads this process may really use: the cgroup CPU quota (the GPU box
+    shows all 256 hardware threads but grants a share), else affinity/cpu_count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(per_core=2500):
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     ctx = mp.get_context('fork')
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:

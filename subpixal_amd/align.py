@@ -1,0 +1,246 @@
+"""Batched counterpart of the reference's per-source fit loop.
+
+``find_linear_fit`` keeps the name, arguments and return triple of
+``subpixal.align.find_linear_fit`` (/root/reference/subpixal/align.py:561-745) but runs
+the loop body align.py:656-699 -- zero the masked pixels, take the four half-pixel
+blots, ``cc.find_displacement`` -- for ALL sources in one kernel launch per cutout
+shape (the iterations are independent; nothing computed for source k feeds k+1 until
+the linear fit at align.py:720).
+
+Not reproduced here (out of scope): the blotting itself
+(``blot.blot_cutout`` -> drizzlepac's C ``tblot``) and astropy WCS objects.  The caller
+supplies the dithered blots, either ready-made or through a ``blot`` callable with the
+reference's ``blot_cutout(dzct, imct)`` signature, and -- optionally -- WCS objects with the
+astropy methods the reference calls (duck-typed).
+
+``iter_linear_fit`` stands in for ``tweakwcs.linearfit.iter_linear_fit`` (align.py:720-724):
+tweakwcs is not available here, so its numerical parity is UNPINNED; the implementation follows
+the documented behaviour (weighted 'shift' / 'rscale' / 'general' fits about a centre with
+iterative sigma clipping).  It is a few-thousand-point 2x3 least squares and stays on the host.
+"""
+import numpy as np
+
+from . import cc
+
+__all__ = ['find_linear_fit', 'iter_linear_fit', 'measure_shifts']
+
+
+# ----------------------------------------------------------------------------
+# robust linear fit of matched point lists (host, float64)
+# ----------------------------------------------------------------------------
+def _weighted_fit(xy, uv, w, fitgeom):
+    """Fit uv ~ F @ xy + t (xy already centred).  Returns (F 2x2, t 2)."""
+    sw = np.sum(w)
+    if fitgeom == 'shift':
+        t = np.sum(w[:, None] * (uv - xy), axis=0) / sw
+        return np.eye(2), t
+    mx = np.sum(w[:, None] * xy, axis=0) / sw
+    mu = np.sum(w[:, None] * uv, axis=0) / sw
+    x = xy - mx
+    u = uv - mu
+    if fitgeom == 'rscale':
+        # similarity transform: u = s R x  (least squares, closed form)
+        sxx = np.sum(w * (x[:, 0] ** 2 + x[:, 1] ** 2))
+        a = np.sum(w * (x[:, 0] * u[:, 0] + x[:, 1] * u[:, 1])) / sxx
+        b = np.sum(w * (x[:, 0] * u[:, 1] - x[:, 1] * u[:, 0])) / sxx
+        f = np.array([[a, -b], [b, a]])
+    elif fitgeom == 'general':
+        # affine: two independent weighted least squares sharing the design matrix
+        sq = np.sqrt(w)[:, None]
+        f = np.linalg.lstsq(sq * x, sq * u, rcond=None)[0].T
+    else:
+        raise ValueError("Unsupported 'fitgeom'. Valid values are: 'shift', 'rscale', 'general'.")
+    t = mu - f @ mx
+    return f, t
+
+
+def iter_linear_fit(xy, uv, wxy=None, wuv=None, fitgeom='general', center=None, nclip=3,
+                    sigma=3.0):
+    """Iteratively sigma-clipped weighted linear fit ``uv ~ F (xy - c) + c + t``.
+
+    Returns a dict with ``offset`` (t), ``fit_matrix`` (F), ``rot`` / ``scale`` / ``skew`` derived from
+    F, ``rms`` (per axis), ``resids``, ``fitmask`` (points kept), ``eff_nclip``, ``center``.
+    """
+    xy = np.asarray(xy, dtype=np.float64)
+    uv = np.asarray(uv, dtype=np.float64)
+    if xy.shape != uv.shape or xy.ndim != 2 or xy.shape[1] != 2:
+        raise ValueError("Input coordinate lists must both have shape (N, 2).")
+    n = xy.shape[0]
+    minpts = {'shift': 1, 'rscale': 2, 'general': 3}.get(fitgeom)
+    if minpts is None:
+        raise ValueError("Unsupported 'fitgeom'. Valid values are: 'shift', 'rscale', 'general'.")
+    if n < minpts:
+        raise ValueError("Not enough points for the requested fit geometry.")
+    w = np.ones(n)
+    for extra in (wxy, wuv):
+        if extra is not None:
+            w = w * np.asarray(extra, dtype=np.float64)
+    c = np.zeros(2) if center is None else np.asarray(center, dtype=np.float64)
+    mask = np.ones(n, dtype=bool)
+    eff = 0
+    for it in range(max(0, int(nclip)) + 1):
+        f, t = _weighted_fit(xy[mask] - c, uv[mask] - c, w[mask], fitgeom)
+        resid = (uv - c) - ((xy - c) @ f.T + t)
+        if it == nclip or sigma is None:
+            break
+        r2 = np.sum(resid ** 2, axis=1)
+        sw = np.sum(w[mask])
+        rms = np.sqrt(np.sum(w[mask] * r2[mask]) / sw)
+        keep = mask & (np.sqrt(r2) <= sigma * rms)
+        if keep.sum() == mask.sum() or keep.sum() < minpts:
+            break
+        mask = keep
+        eff += 1
+    sw = np.sum(w[mask])
+    rms = np.sqrt(np.sum(w[mask, None] * resid[mask] ** 2, axis=0) / sw)
+    rotx = np.degrees(np.arctan2(f[1, 0], f[0, 0]))
+    roty = np.degrees(np.arctan2(-f[0, 1], f[1, 1]))
+    sx = float(np.hypot(f[0, 0], f[1, 0]))
+    sy = float(np.hypot(f[0, 1], f[1, 1]))
+    return {
+        'offset': t, 'shift': t, 'fit_matrix': f, 'matrix': f,
+        'rot': 0.5 * (rotx + roty), 'rotxy': (rotx, roty, 0.5 * (rotx + roty), roty - rotx),
+        'scale': (np.sqrt(abs(np.linalg.det(f))), sx, sy), 'skew': roty - rotx,
+        'rms': rms, 'resids': resid, 'fitmask': mask, 'eff_nclip': eff, 'center': c,
+        'fitgeom': fitgeom, 'nmatches': int(mask.sum()),
+    }
+
+
+# ----------------------------------------------------------------------------
+# the batched loop body of align.py:656-699
+# ----------------------------------------------------------------------------
+def measure_shifts(ref_tiles, im4_tiles, cc_type='NCC', full_output=False):
+    """Displacements for lists of same-or-mixed-shape cutouts: ``ref_tiles[k]`` is a 2-D
+    array, ``im4_tiles[k]`` its four dithered blots (00, 10, 01, 11).  One launch per
+    distinct shape.  Returns ``dxdy [N, 2]`` (and the list of interlaced images)."""
+    n = len(ref_tiles)
+    dxdy = np.empty((n, 2), dtype=np.float64)
+    iccs = [None] * n
+    groups = {}
+    for k, r in enumerate(ref_tiles):
+        shapes = {np.shape(r)} | {np.shape(b) for b in im4_tiles[k]}
+        if len(shapes) != 1:
+            raise ValueError("All cutouts must have same shape.")       # cc.py:103-105
+        groups.setdefault(np.shape(r), []).append(k)
+    for shape, idx in groups.items():
+        ref = np.stack([np.asarray(ref_tiles[k], dtype=np.float32) for k in idx])
+        im4 = np.stack([np.stack([np.asarray(b, dtype=np.float32) for b in im4_tiles[k]])
+                        for k in idx])
+        res = cc.find_displacement_batch(ref, im4, cc_type=cc_type, full_output=full_output)
+        d, icc = (res if full_output else (res, None))
+        dxdy[idx] = d
+        if full_output:
+            for j, k in enumerate(idx):
+                iccs[k] = icc[j]
+    return (dxdy, iccs) if full_output else dxdy
+
+
+def _image_xy(ct, x, y, wcslin):
+    """Position (x, y) of cutout ``ct`` in the tangent-plane image coordinates of ``wcslin``
+    (align.py:692-699); without WCS objects, plain pixel coordinates of the parent image."""
+    if wcslin is not None and getattr(ct, 'wcs', None) is not None:
+        ra, dec = ct.pix2world(x, y)
+        return np.array(wcslin.wcs_world2pix(ra, dec, 1), dtype=np.float64).reshape(2)
+    return np.array([x + ct.blc[0] - ct.dx + 1.0, y + ct.blc[1] - ct.dy + 1.0])
+
+
+def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
+                    nclip=3, sigma=3.0, use_weights=True, cc_type='NCC', blot=None):
+    """Linear fit to the displacements (found by cross-correlation) between ``img_cutouts`` and
+    the blots of ``drz_cutouts`` onto them.  Same arguments and return value
+    ``(fit, interlaced_cc, nonshifted_blts)`` as the reference (align.py:561-745).
+
+    blot : callable ``blot(dzct, imct) -> cutout`` with the semantics of the reference's
+        ``blot_cutout``; called four times per source with the image cutout's grid displaced by
+        (0,0), (-1/2,0), (-1/2,-1/2), (0,-1/2) exactly as align.py:664-679.  When None, each element
+        of ``drz_cutouts`` must already be the 4-sequence ``(blt00, blt10, blt01, blt11)``.
+    """
+    if not hasattr(img_cutouts, '__iter__'):
+        img_cutouts = [img_cutouts]
+    if not hasattr(drz_cutouts, '__iter__') or (blot is not None and hasattr(drz_cutouts, 'data')):
+        drz_cutouts = [drz_cutouts]
+    img_cutouts = list(img_cutouts)
+    drz_cutouts = list(drz_cutouts)
+    if len(img_cutouts) != len(drz_cutouts):                               # align.py:631-633
+        raise ValueError("The number of image cutouts must match the number "
+                         "of drizzled cutouts.")
+    npts = len(img_cutouts)
+    if wcslin is None and blot is not None and getattr(drz_cutouts[0], 'wcs', None) is not None:
+        wcslin = drz_cutouts[0].wcs                                        # align.py:636-639
+    if wcslin is not None and hasattr(wcslin, 'deepcopy'):
+        wcslin = wcslin.deepcopy()
+
+    blts = []
+    for imct, dz in zip(img_cutouts, drz_cutouts):
+        if blot is None:
+            if len(dz) != 4:
+                raise ValueError("Without a 'blot' callable each element of drz_cutouts must be "
+                                 "the four dithered blots (blt00, blt10, blt01, blt11).")
+            blts.append(tuple(dz))
+            continue
+        dx0, dy0 = imct.dx, imct.dy                                        # align.py:658-679
+        dz.data[dz.mask] = 0
+        b00 = blot(dz, imct)
+        imct.dx -= 0.5
+        b10 = blot(dz, imct)
+        imct.dy -= 0.5
+        b11 = blot(dz, imct)
+        imct.dx = dx0
+        b01 = blot(dz, imct)
+        imct.dy = dy0
+        blts.append((b00, b10, b01, b11))
+
+    def data_of(c):
+        return c.data if hasattr(c, 'data') and not isinstance(c, np.ndarray) else np.asarray(c)
+
+    img_dxy, interlaced_cc = measure_shifts(
+        [data_of(c) for c in img_cutouts],
+        [[data_of(b) for b in four] for four in blts], cc_type=cc_type, full_output=True)
+    nonshifted_blts = [four[0] for four in blts]
+
+    xyim = np.empty((npts, 2))
+    xyref = np.empty((npts, 2))
+    for k, imct in enumerate(img_cutouts):
+        if hasattr(imct, 'cutout_src_pos'):
+            x1, y1 = imct.cutout_src_pos
+            xyim[k] = _image_xy(imct, x1, y1, wcslin)
+            xyref[k] = _image_xy(imct, x1 + img_dxy[k, 0], y1 + img_dxy[k, 1], wcslin)
+        else:                       # bare arrays: positions are the cutout centres
+            ny, nx = np.shape(data_of(imct))
+            xyim[k] = ((nx - 1) / 2.0, (ny - 1) / 2.0)
+            xyref[k] = xyim[k] + img_dxy[k]
+    ref_dxy = xyim - xyref
+
+    weights = None
+    if use_weights:                                                        # align.py:703-716
+        carriers = drz_cutouts if blot is not None else [four[0] for four in blts]
+        weights = [getattr(c, 'src_weight', None) for c in carriers]
+        if all(w is None for w in weights):
+            weights = None
+        elif any(w is None for w in weights):
+            raise ValueError("Not all cutouts have weights set. All cutouts "
+                             "must either have non-negative weights or be "
+                             "None.")
+        elif any(w < 0 for w in weights):
+            raise ValueError("Weights must be non-negative.")
+        else:
+            weights = np.asarray(weights, dtype=np.float64)
+
+    center = None
+    if wcslin is not None and hasattr(wcslin, 'wcs'):
+        center = np.array(wcslin.wcs.crpix)
+    fit = iter_linear_fit(xyim, xyref, wxy=None, wuv=weights, fitgeom=fitgeom, center=center,
+                          nclip=nclip, sigma=sigma)
+    fit['subpixal_img_dxy'] = img_dxy
+    fit['subpixal_ref_dxy'] = ref_dxy
+    m = fit['fitmask']
+    if weights is None:                                                    # align.py:730-743
+        fit['irmse'] = float(np.sqrt(2 * np.mean(img_dxy[m] ** 2)))
+    else:
+        wt = np.sum(weights)
+        if len(weights) == 0 or wt == 0.0:
+            fit['irmse'] = float('nan')
+        else:
+            w = weights / wt
+            fit['irmse'] = float(np.sqrt(np.sum(np.dot(w[m], img_dxy[m] ** 2))))
+    return fit, interlaced_cc, nonshifted_blts

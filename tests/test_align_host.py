@@ -1,0 +1,64 @@
+"""Host-side pieces of the alignment loop (no GPU): the robust linear fit and the
+argument conventions of find_linear_fit."""
+import numpy as np
+import pytest
+
+from subpixal_amd.align import iter_linear_fit, find_linear_fit
+
+
+def _points(n, seed=0):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(0, 4096, (n, 2))
+
+
+def test_fit_geometries_recover_known_transforms():
+    xy = _points(200)
+    c = np.array([2048.0, 2048.0])
+    th = np.radians(0.01)
+    cases = {
+        'shift': (np.eye(2), np.array([0.37, -1.21])),
+        'rscale': (1.0002 * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]),
+                   np.array([-0.5, 0.25])),
+        'general': (np.array([[1.0003, 2e-5], [-4e-5, 0.9998]]), np.array([1.5, -0.75])),
+    }
+    for geom, (f, t) in cases.items():
+        uv = (xy - c) @ f.T + c + t
+        fit = iter_linear_fit(xy, uv, fitgeom=geom, center=c)
+        np.testing.assert_allclose(fit['fit_matrix'], f, atol=1e-12)
+        np.testing.assert_allclose(fit['offset'], t, atol=1e-9)
+        assert fit['fitmask'].all() and fit['eff_nclip'] == 0
+        assert np.all(fit['rms'] < 1e-9)
+
+
+def test_sigma_clipping_rejects_outliers_and_weights_matter():
+    xy = _points(300, 1)
+    rng = np.random.default_rng(2)
+    t = np.array([0.8, -0.3])
+    uv = xy + t + 0.01 * rng.standard_normal(xy.shape)
+    bad = rng.choice(300, 12, replace=False)
+    uv[bad] += rng.uniform(3, 6, (12, 2))
+    fit = iter_linear_fit(xy, uv, fitgeom='shift', nclip=3, sigma=3.0)
+    assert not fit['fitmask'][bad].any()
+    assert fit['fitmask'].sum() >= 280
+    np.testing.assert_allclose(fit['offset'], t, atol=3e-3)
+    unclipped = iter_linear_fit(xy, uv, fitgeom='shift', nclip=0)
+    assert np.abs(unclipped['offset'] - t).max() > 0.05
+    w = np.ones(300)
+    w[bad] = 0.0
+    weighted = iter_linear_fit(xy, uv, wuv=w, fitgeom='shift', nclip=0)
+    np.testing.assert_allclose(weighted['offset'], t, atol=3e-3)
+
+
+def test_argument_errors():
+    xy = _points(5)
+    with pytest.raises(ValueError):
+        iter_linear_fit(xy, xy[:4])
+    with pytest.raises(ValueError):
+        iter_linear_fit(xy, xy, fitgeom='affine')
+    with pytest.raises(ValueError):
+        iter_linear_fit(xy[:2], xy[:2], fitgeom='general')
+    a = np.zeros((8, 8), np.float32)
+    with pytest.raises(ValueError, match="number of image cutouts"):
+        find_linear_fit([a, a], [(a, a, a, a)])
+    with pytest.raises(ValueError, match="four dithered blots"):
+        find_linear_fit([a], [(a, a)])
