@@ -165,6 +165,15 @@ def main():
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
 
     if rank == 0:
+        # HBM traffic of the same launch from the committed PMC passes (rocprofv3 cannot run
+        # inside this process); only quoted for the configuration it was measured on
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')))
+            if pmc.get('pairs_per_launch') == n_local:
+                traffic = pmc['hbm_bytes_per_launch']
+        except (OSError, ValueError, KeyError):
+            pass
         value = n_total * args.steps / elapsed
         achieved = n_local * BYTES_PER_PAIR / (kern_ms * 1e-3) / 1e9
         out = {
@@ -192,7 +201,9 @@ def main():
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': None,
+                'traffic': traffic,
+                'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01/pmc_traffic.json)',
+                'algorithmic_bytes_per_launch': n_local * BYTES_PER_PAIR,
                 'kernel': 'spx::pair_kernel<2,1>',
                 'kernel_ms': kern_ms,
                 'bytes_per_pair': BYTES_PER_PAIR,
