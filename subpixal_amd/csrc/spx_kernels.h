@@ -85,53 +85,41 @@ template <int DBG> struct PhaseClock {
 };
 
 // ---------------------------------------------------------------------------
-// complex helpers
+// complex helpers.  The primitives (cmul, cmulc, add_mi, add_pi, ...) are single
+// packed VOP3P instructions on gfx950 (spx_rt_hip.h).
 // ---------------------------------------------------------------------------
-SPX_DEVICE cf cmul(cf a, cf w) {
-    return cf{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x};
-}
-SPX_DEVICE cf cmulc(cf a, cf w) {   // a * conj(w)
-    return cf{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y};
-}
-template <int DIR> SPX_DEVICE cf ctw(cf a, cf w) {   // a * w (DIR>0) or a * conj(w)
-    return DIR > 0 ? cmul(a, w) : cmulc(a, w);
-}
-// multiply by -i (forward) / +i (inverse)
-template <int DIR> SPX_DEVICE cf mul_mi(cf a) {
-    return DIR > 0 ? cf{a.y, -a.x} : cf{-a.y, a.x};
-}
-// multiply by w8^1 = (1 - i)/sqrt2 (forward) / its conjugate
-template <int DIR> SPX_DEVICE cf mul_w8_1(cf a) {
-    const float h = 0.70710678118654752440f;
-    return DIR > 0 ? cf{(a.x + a.y) * h, (a.y - a.x) * h}
-                   : cf{(a.x - a.y) * h, (a.x + a.y) * h};
-}
-// multiply by w8^3 = (-1 - i)/sqrt2 (forward) / its conjugate
-template <int DIR> SPX_DEVICE cf mul_w8_3(cf a) {
-    const float h = 0.70710678118654752440f;
-    return DIR > 0 ? cf{(a.y - a.x) * h, -(a.x + a.y) * h}
-                   : cf{-(a.x + a.y) * h, (a.x - a.y) * h};
-}
+SPX_DEVICE cf cmul(cf a, cf w) { return rt::cmul(a, w); }
+SPX_DEVICE cf cmulc(cf a, cf w) { return rt::cmulc(a, w); }
+// s + rot(d) and s - rot(d), rot = multiply by -i (forward, DIR > 0) or +i (inverse)
+template <int DIR> SPX_DEVICE cf rot_add(cf s, cf d) { return DIR > 0 ? rt::add_mi(s, d) : rt::add_pi(s, d); }
+template <int DIR> SPX_DEVICE cf rot_sub(cf s, cf d) { return DIR > 0 ? rt::add_pi(s, d) : rt::add_mi(s, d); }
 
-// 4-point DFT, natural order in and out
-template <int DIR>
+// 4-point DFT, natural order in and out; `c2r` is c2 BEFORE its rotation by -+i when
+// ROT2 is set (lets the radix-8 stage hand over (a2 - a6) unrotated)
+template <int DIR, bool ROT2>
 SPX_DEVICE void fft4(cf c0, cf c1, cf c2, cf c3, cf& y0, cf& y1, cf& y2, cf& y3) {
-    cf s0 = c0 + c2, s1 = c0 - c2, s2 = c1 + c3, s3 = mul_mi<DIR>(c1 - c3);
+    const cf s0 = ROT2 ? rot_add<DIR>(c0, c2) : c0 + c2;
+    const cf s1 = ROT2 ? rot_sub<DIR>(c0, c2) : c0 - c2;
+    const cf s2 = c1 + c3, d = c1 - c3;
     y0 = s0 + s2;
     y2 = s0 - s2;
-    y1 = s1 + s3;
-    y3 = s1 - s3;
+    y1 = rot_add<DIR>(s1, d);
+    y3 = rot_sub<DIR>(s1, d);
 }
 
 // 8-point DFT, natural order in and out (radix-2 DIF + two radix-4):
 // X[k] = sum_j a[j] e^{-DIR 2 pi i j k / 8}
 template <int DIR> SPX_DEVICE void fft8(cf (&a)[8]) {
-    cf b0 = a[0] + a[4], b4 = a[0] - a[4];
-    cf b1 = a[1] + a[5], b5 = mul_w8_1<DIR>(a[1] - a[5]);
-    cf b2 = a[2] + a[6], b6 = mul_mi<DIR>(a[2] - a[6]);
-    cf b3 = a[3] + a[7], b7 = mul_w8_3<DIR>(a[3] - a[7]);
-    fft4<DIR>(b0, b1, b2, b3, a[0], a[2], a[4], a[6]);
-    fft4<DIR>(b4, b5, b6, b7, a[1], a[3], a[5], a[7]);
+    const float h = 0.70710678118654752440f;
+    const cf b0 = a[0] + a[4], d4 = a[0] - a[4];
+    const cf b1 = a[1] + a[5], d5 = a[1] - a[5];
+    const cf b2 = a[2] + a[6], d6 = a[2] - a[6];
+    const cf b3 = a[3] + a[7], d7 = a[3] - a[7];
+    // w8^1 d5 = h (d5 + rot d5),  w8^3 d7 = h (-d7 + rot d7)
+    const cf b5 = rot_add<DIR>(d5, d5) * h;
+    const cf b7 = (DIR > 0 ? rt::neg_add_mi(d7) : rt::neg_add_pi(d7)) * h;
+    fft4<DIR, false>(b0, b1, b2, b3, a[0], a[2], a[4], a[6]);
+    fft4<DIR, true>(d4, b5, d6, b7, a[1], a[3], a[5], a[7]);
 }
 
 // radix-8 along the first (y) digit of an 8x8 register tile
@@ -534,8 +522,7 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk) {
     for (int ka = 0; ka < 8; ++ka)
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) {
-            const cf a = v[ka][kb];
-            v[ka][kb] = cf{a.x * a.x - a.y * a.y, 2.0f * a.x * a.y};
+            v[ka][kb] = cmul(v[ka][kb], v[ka][kb]);
         }
 
     SPX_DBG_STOP(6);

@@ -72,6 +72,52 @@ SPX_DEVICE unsigned long long clock_stamp() {
 }
 SPX_DEVICE void atomic_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 
+// ---------------------------------------------------------------------------
+// Packed complex arithmetic on (re, im) register pairs: one VOP3P instruction each,
+// using op_sel (which half feeds which lane) and neg_lo/neg_hi instead of the
+// v_mov/v_xor + scalar mul/fma sequences hipcc emits for the same expressions.
+// ---------------------------------------------------------------------------
+// a * w
+SPX_DEVICE f32x2 cmul(f32x2 a, f32x2 w) {
+    f32x2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a * conj(w)
+SPX_DEVICE f32x2 cmulc(f32x2 a, f32x2 w) {
+    f32x2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// s + (-i) d = (s.x + d.y, s.y - d.x)
+SPX_DEVICE f32x2 add_mi(f32x2 s, f32x2 d) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(s), "v"(d));
+    return r;
+}
+// s + (+i) d = (s.x - d.y, s.y + d.x)
+SPX_DEVICE f32x2 add_pi(f32x2 s, f32x2 d) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(s), "v"(d));
+    return r;
+}
+// -d + (-i) d = (d.y - d.x, -d.x - d.y)
+SPX_DEVICE f32x2 neg_add_mi(f32x2 d) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,1]" : "=v"(r) : "v"(d));
+    return r;
+}
+// -d + (+i) d = (-d.x - d.y, d.x - d.y)
+SPX_DEVICE f32x2 neg_add_pi(f32x2 d) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,1] neg_hi:[1,0]" : "=v"(r) : "v"(d));
+    return r;
+}
+
 // forces `v` to be materialised here (and nothing else)
 SPX_DEVICE void consume(float v) { asm volatile("" ::"v"(v)); }
 

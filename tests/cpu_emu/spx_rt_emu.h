@@ -72,6 +72,12 @@ SPX_DEVICE int launder_lane(int v) { return v; }
 SPX_DEVICE int launder_uniform(int v) { return v; }
 SPX_DEVICE unsigned long long clock_stamp() { return 0; }
 SPX_DEVICE void atomic_add_u64(unsigned long long* p, unsigned long long v) { (void)p; (void)v; }
+SPX_DEVICE f32x2 cmul(f32x2 a, f32x2 w) { return f32x2{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+SPX_DEVICE f32x2 cmulc(f32x2 a, f32x2 w) { return f32x2{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y}; }
+SPX_DEVICE f32x2 add_mi(f32x2 s, f32x2 d) { return f32x2{s.x + d.y, s.y - d.x}; }
+SPX_DEVICE f32x2 add_pi(f32x2 s, f32x2 d) { return f32x2{s.x - d.y, s.y + d.x}; }
+SPX_DEVICE f32x2 neg_add_mi(f32x2 d) { return f32x2{d.y - d.x, -d.x - d.y}; }
+SPX_DEVICE f32x2 neg_add_pi(f32x2 d) { return f32x2{-d.x - d.y, d.x - d.y}; }
 SPX_DEVICE void consume(float v) { (void)v; }
 SPX_DEVICE void sched_fence() {}
 
