@@ -66,7 +66,7 @@ extern "C" {
 #define SPX_E_WORKSPACE (-4)  /* workspace missing or too small            */
 
 /* largest cutout side and upsampling factor the kernels accept */
-#define SPX_MAX_SIDE 64
+#define SPX_MAX_SIDE 128
 #define SPX_MAX_UPSAMPLE 59
 
 int spx_abi_version(void);
@@ -77,12 +77,21 @@ int spx_init(int device);
 int spx_prepare(int upsample);
 const char* spx_last_error(void);
 
-/* Bytes of scratch the batched calls need (0 when none). */
-size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx);
+/*
+ * Bytes of device scratch the batched calls need (0 when none).  Cutouts up to 64x64
+ * are processed entirely in registers/LDS; larger ones (the 128 tile, FFT period 256)
+ * keep per-workgroup class planes and the 256x256 convolution in an L2-resident
+ * workspace of 768 KiB per resident workgroup (independent of nbatch beyond the grid).
+ * For the reference mode `need_icc` adds room for the interlaced images when the
+ * caller does not want them back (out_icc == NULL).
+ */
+size_t spx_workspace_bytes_xcorr(int64_t nbatch, int ny, int nx);
+size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int need_icc);
 
 /*
  * Pair mode.  ref, img: float32 [nbatch][ny][nx].  For every pair: linear
- * cross-correlation on the zero-padded 128x128 grid, arg-max over the flipped
+ * cross-correlation on the zero-padded grid (period 128 for cutouts up to 64 px per
+ * side, 256 above), arg-max over the flipped
  * 'same' window, U-times trigonometric upsampling around it, 5x5 quadratic fit
  * (find_peak(., 5, 'all')), shift = peak/U - (n-1)//2.
  *   out_dxdy   : float64 [nbatch][2]  (dx, dy)
@@ -91,14 +100,15 @@ size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx);
  */
 int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
                          int upsample, int cc_type, double* out_dxdy, int32_t* out_status,
-                         void* stream);
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Reference mode (cc.find_displacement).  ref: float32 [nbatch][ny][nx];
  * im4: float32 [nbatch][4][ny][nx] in the order image00, image10, image01,
  * image11.  out_icc: float32 [nbatch][2ny][2nx] interlaced cross-correlation
- * images (full_output=True), or NULL, in which case `workspace` of
- * spx_workspace_bytes_displacement5() bytes must be given.
+ * images (full_output=True), or NULL; `workspace` must hold
+ * spx_workspace_bytes_displacement5(nbatch, ny, nx, out_icc == NULL) bytes (may be NULL
+ * when that is 0).
  * 3 <= ny, nx <= SPX_MAX_SIDE.
  */
 int spx_find_displacement5_f32(const float* ref, const float* im4, int64_t nbatch, int ny,

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libsubpixal_hip.so')
 
 ABI_VERSION = 1
-MAX_SIDE = 64
+MAX_SIDE = 128
 MAX_UPSAMPLE = 59
 
 CC_CODES = {'CC': 0, 'NCC': 1, 'ZNCC': 2}
@@ -25,9 +25,10 @@ _SIGNATURES = {
     'spx_init': (_c.c_int, [_c.c_int]),
     'spx_prepare': (_c.c_int, [_c.c_int]),
     'spx_last_error': (_c.c_char_p, []),
-    'spx_workspace_bytes_displacement5': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int]),
+    'spx_workspace_bytes_xcorr': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int]),
+    'spx_workspace_bytes_displacement5': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int]),
     'spx_xcorr_refine_f32': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
-                                        _c.c_int, _vp, _vp, _vp]),
+                                        _c.c_int, _vp, _vp, _vp, _c.c_size_t, _vp]),
     'spx_find_displacement5_f32': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int,
                                               _c.c_int, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     'spx_find_peak_f64': (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,

@@ -19,6 +19,14 @@ def _cc_code(cc_type):
     return _ffi.CC_CODES.get(str(cc_type).upper(), 0)
 
 
+def _workspace(nbytes, dev):
+    """Device scratch for cutouts above 64 px (the 128 tile keeps its class planes in an
+    L2-resident workspace); (None, 0) when the call needs none."""
+    if nbytes == 0:
+        return None, 0
+    return torch.empty((int(nbytes),), dtype=torch.uint8, device=dev), int(nbytes)
+
+
 def _finish(t, like_torch):
     return t if like_torch else t.cpu().numpy()
 
@@ -27,7 +35,7 @@ def xcorr_refine_batch(ref, img, upsample=1, cc_type='CC', return_status=False):
     """Shifts of ``img[k]`` relative to ``ref[k]`` for a batch of cutout pairs.
 
     ref, img : ``[N, ny, nx]`` float32, torch CUDA tensors (used in place) or
-        numpy arrays (copied to the device).  5 <= ny, nx <= 64.
+        numpy arrays (copied to the device).  5 <= ny, nx <= 128.
     upsample : the cross-correlation is refined on a grid ``upsample`` times
         finer than the pixel grid before the 5x5 quadratic peak fit;
         ``upsample=2`` is the reference's half-pixel interlace (cc.py:121-126),
@@ -46,9 +54,10 @@ def xcorr_refine_batch(ref, img, upsample=1, cc_type='CC', return_status=False):
     status = torch.empty((n,), dtype=torch.int32, device=r.device)
     lib = _ffi.load()
     with torch.cuda.device(r.device):
+        ws, ws_bytes = _workspace(lib.spx_workspace_bytes_xcorr(n, ny, nx), r.device)
         _ffi.check(lib.spx_xcorr_refine_f32(
             device.ptr(r), device.ptr(m), n, ny, nx, int(upsample), _cc_code(cc_type),
-            device.ptr(out), device.ptr(status), device.stream_ptr()))
+            device.ptr(out), device.ptr(status), device.ptr(ws), ws_bytes, device.stream_ptr()))
     if return_status:
         return _finish(out, like_torch), _finish(status, like_torch)
     return _finish(out, like_torch)
@@ -71,9 +80,10 @@ def find_displacement_batch(ref, im4, cc_type='NCC', full_output=False, return_s
     icc = torch.empty((n, 2 * ny, 2 * nx), dtype=torch.float32, device=r.device)
     lib = _ffi.load()
     with torch.cuda.device(r.device):
+        ws, ws_bytes = _workspace(lib.spx_workspace_bytes_displacement5(n, ny, nx, 0), r.device)
         _ffi.check(lib.spx_find_displacement5_f32(
             device.ptr(r), device.ptr(m), n, ny, nx, _cc_code(cc_type), device.ptr(out),
-            device.ptr(status), device.ptr(icc), 0, 0, device.stream_ptr()))
+            device.ptr(status), device.ptr(icc), device.ptr(ws), ws_bytes, device.stream_ptr()))
     res = [_finish(out, like_torch)]
     if full_output:
         res.append(_finish(icc, like_torch))

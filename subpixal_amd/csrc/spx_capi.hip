@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC spx_capi.hip
 #include "spx_rt_hip.h"
 #include "spx_kernels.h"
+#include "spx_kernels128.h"
 #include "spx_aux_kernels.h"
 #include "spx_tables.h"
 #include "../../include/subpixal_hip.h"
@@ -30,7 +31,9 @@ int hip_fail(hipError_t e, const char* what) {
 
 struct DeviceTables {
     spx::cf* tw128 = nullptr;                 // w_128^j
-    std::map<int, float*> ktab;               // upsample -> [2][W][64]
+    spx::cf* tw256 = nullptr;                 // w_256^j (128 tile)
+    std::map<int, float*> ktab;               // upsample -> lane-major tables, 64 tile
+    std::map<int, float*> ktab256;            // upsample -> lane-major tables, 128 tile
     int num_cu = 256;
     bool lds_attr_set = false;
 };
@@ -49,6 +52,10 @@ int current_tables(DeviceTables** out) {
         SPX_HIP(hipMalloc(&p, tw.size() * sizeof(float)));
         SPX_HIP(hipMemcpy(p, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
         t.tw128 = reinterpret_cast<spx::cf*>(p);
+        std::vector<float> tw2 = spx::host::make_twiddles(256);
+        SPX_HIP(hipMalloc(&p, tw2.size() * sizeof(float)));
+        SPX_HIP(hipMemcpy(p, tw2.data(), tw2.size() * sizeof(float), hipMemcpyHostToDevice));
+        t.tw256 = reinterpret_cast<spx::cf*>(p);
         hipDeviceProp_t prop;
         SPX_HIP(hipGetDeviceProperties(&prop, dev));
         t.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -74,6 +81,36 @@ int ktab_for(DeviceTables* t, int upsample, const float** out) {
     return 0;
 }
 
+int ktab256_for(DeviceTables* t, int upsample, const float** out) {
+    *out = nullptr;
+    const int wb = spx::host::window_blocks(upsample);
+    if (wb <= 0) return 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = t->ktab256.find(upsample);
+    if (it == t->ktab256.end()) {
+        std::vector<float> k = spx::host::make_ktab256(upsample, 16 * wb);
+        void* p = nullptr;
+        SPX_HIP(hipMalloc(&p, k.size() * sizeof(float)));
+        SPX_HIP(hipMemcpy(p, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
+        it = t->ktab256.emplace(upsample, reinterpret_cast<float*>(p)).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+// workgroups of a 128-tile launch (each owns one 768 KiB workspace slot)
+int64_t grid128(int num_cu, int64_t nbatch) {
+    const int64_t cap = (int64_t)num_cu * 2;
+    return nbatch < cap ? nbatch : cap;
+}
+int device_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        return 256;
+    return n;
+}
+
 template <typename K> int allow_lds(K kernel, int bytes) {
     SPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -97,6 +134,20 @@ int launch_pair(const DeviceTables* t, const float* ref, const float* img, int64
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(grid_for(t, nbatch)), dim3(spx::kThreads), lds, s, ref, img,
                        nbatch, ny, nx, U, cc_type, t->tw128, ktab, out, status);
+    SPX_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int WB>
+int launch_pair128(const DeviceTables* t, const float* ref, const float* img, int64_t nbatch, int ny,
+                   int nx, int U, int cc_type, const float* ktab, double* out, int32_t* status,
+                   float* ws, hipStream_t s) {
+    const int lds = spx::Lds128::total(16 * WB);
+    auto kern = spx::pair128_kernel<WB>;
+    int rc = allow_lds(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid128(t->num_cu, nbatch)), dim3(spx::kThreads), lds, s,
+                       ref, img, nbatch, ny, nx, U, cc_type, t->tw256, ktab, out, status, ws);
     SPX_HIP(hipGetLastError());
     return 0;
 }
@@ -131,28 +182,52 @@ int spx_prepare(int upsample) {
     return ktab_for(t, upsample, &k);
 }
 
-size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx) {
+size_t spx_workspace_bytes_xcorr(int64_t nbatch, int ny, int nx) {
     if (nbatch <= 0 || ny <= 0 || nx <= 0) return 0;
-    return (size_t)nbatch * 4u * (size_t)ny * (size_t)nx * sizeof(float);
+    if (ny <= 64 && nx <= 64) return 0;
+    return (size_t)grid128(device_cus(), nbatch) * spx::kWs128Bytes;
+}
+
+size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int need_icc) {
+    if (nbatch <= 0 || ny <= 0 || nx <= 0) return 0;
+    size_t b = spx_workspace_bytes_xcorr(nbatch, ny, nx);
+    if (need_icc) b += (size_t)nbatch * 4u * (size_t)ny * (size_t)nx * sizeof(float);
+    return b;
 }
 
 int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
                          int upsample, int cc_type, double* out_dxdy, int32_t* out_status,
-                         void* stream) {
+                         void* workspace, size_t workspace_bytes, void* stream) {
     if (nbatch < 0 || (nbatch > 0 && (!ref || !img || !out_dxdy)))
         return fail(SPX_E_ARG, "null pointer or negative batch");
     if (ny < 5 || nx < 5 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
-        return fail(SPX_E_SHAPE, "pair mode supports cutouts of 5..64 pixels per side");
+        return fail(SPX_E_SHAPE, "pair mode supports cutouts of 5..128 pixels per side");
     const int wb = spx::host::window_blocks(upsample);
     if (wb < 0) return fail(SPX_E_SHAPE, "upsample must be in [1, 59]");
     if (nbatch == 0) return 0;
+    const bool big = ny > 64 || nx > 64;            // 128 tile, FFT period 256
+    if (big && (!workspace || workspace_bytes < spx_workspace_bytes_xcorr(nbatch, ny, nx)))
+        return fail(SPX_E_WORKSPACE, "cutouts above 64 px need spx_workspace_bytes_xcorr() bytes");
     DeviceTables* t = nullptr;
     int rc = current_tables(&t);
     if (rc) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (big) {
+        const float* ktab = nullptr;
+        rc = ktab256_for(t, upsample, &ktab);
+        if (rc) return rc;
+        float* ws = reinterpret_cast<float*>(workspace);
+        switch (wb) {
+        case 0: return launch_pair128<0>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        case 1: return launch_pair128<1>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        case 2: return launch_pair128<2>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        case 3: return launch_pair128<3>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        default: return launch_pair128<4>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        }
+    }
     const float* ktab = nullptr;
     rc = ktab_for(t, upsample, &ktab);
     if (rc) return rc;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (wb) {
     case 0: return launch_pair<0>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
     case 1: return launch_pair<1>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
@@ -193,24 +268,35 @@ int spx_find_displacement5_f32(const float* ref, const float* im4, int64_t nbatc
     if (nbatch < 0 || (nbatch > 0 && (!ref || !im4 || !out_dxdy)))
         return fail(SPX_E_ARG, "null pointer or negative batch");
     if (ny < 3 || nx < 3 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
-        return fail(SPX_E_SHAPE, "5-image mode supports cutouts of 3..64 pixels per side");
+        return fail(SPX_E_SHAPE, "5-image mode supports cutouts of 3..128 pixels per side");
     if (nbatch == 0) return 0;
-    float* icc = out_icc;
-    if (!icc) {
-        if (!workspace || workspace_bytes < spx_workspace_bytes_displacement5(nbatch, ny, nx))
-            return fail(SPX_E_WORKSPACE, "out_icc is NULL and the workspace is too small");
-        icc = reinterpret_cast<float*>(workspace);
-    }
+    const size_t need = spx_workspace_bytes_displacement5(nbatch, ny, nx, out_icc == nullptr);
+    if (need > 0 && (!workspace || workspace_bytes < need))
+        return fail(SPX_E_WORKSPACE, "workspace missing or smaller than spx_workspace_bytes_displacement5()");
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
+    const size_t tile_ws = spx_workspace_bytes_xcorr(nbatch, ny, nx);
+    float* icc = out_icc ? out_icc : reinterpret_cast<float*>(wsb + tile_ws);
     DeviceTables* t = nullptr;
     int rc = current_tables(&t);
     if (rc) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (ny > 64 || nx > 64) {
+        const int lds = spx::Lds128::total(0);
+        auto kern = spx::disp5_128_kernel;
+        rc = allow_lds(kern, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid128(t->num_cu, nbatch)), dim3(spx::kThreads), lds, s,
+                           ref, im4, nbatch, ny, nx, cc_type, t->tw256, icc, out_dxdy, out_status,
+                           reinterpret_cast<float*>(wsb));
+        SPX_HIP(hipGetLastError());
+        return 0;
+    }
     const int lds = spx::Lds<2>::total(0);
     auto kern = spx::disp5_kernel<2>;
     rc = allow_lds(kern, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid_for(t, nbatch)), dim3(spx::kThreads), lds,
-                       reinterpret_cast<hipStream_t>(stream), ref, im4, nbatch, ny, nx, cc_type,
-                       t->tw128, icc, out_dxdy, out_status);
+    hipLaunchKernelGGL(kern, dim3(grid_for(t, nbatch)), dim3(spx::kThreads), lds, s, ref, im4, nbatch,
+                       ny, nx, cc_type, t->tw128, icc, out_dxdy, out_status);
     SPX_HIP(hipGetLastError());
     return 0;
 }

@@ -140,6 +140,25 @@ template <int DIR> SPX_DEVICE void fft8_x(cf (&v)[8][8]) {
     for (int y = 0; y < 8; ++y) fft8<DIR>(v[y]);
 }
 
+// lane <-> register transposition of an 8x8 complex tile through the wave's own LDS
+// buffer (64 rows of XS floats): (lane L, register R) -> (lane R, register L); real and
+// imaginary parts in two passes (ds_write2_b32 / ds_read_b128, conflict-free at XS = 68).
+template <int XS> SPX_DEVICE void transpose_tile(cf (&v)[8][8], float* xch, int lane) {
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int r = 0; r < 64; ++r)
+            xch[r * XS + lane] = part ? v[r >> 3][r & 7].y : v[r >> 3][r & 7].x;
+        rt::wave_sync();
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            const float t = xch[lane * XS + r];
+            if (part) v[r >> 3][r & 7].y = t; else v[r >> 3][r & 7].x = t;
+        }
+        rt::wave_sync();
+    }
+}
+
 // ---------------------------------------------------------------------------
 // LDS map (bytes).  Everything is carved from one dynamic region.
 // ---------------------------------------------------------------------------
@@ -170,8 +189,7 @@ template <int C> struct Lds {
 };
 
 // scratch (1 KiB) sub-offsets
-constexpr int SCR_RED_F = 0;      // float[4]  per-wave reduction values
-constexpr int SCR_RED_I = 16;     // int[4]    per-wave reduction indices
+constexpr int SCR_RED_F = 0;      // 2 slots x (float[4] values + int[4] indices)
 constexpr int SCR_INT = 64;       // int[16]   broadcast integers
 constexpr int SCR_RED_D = 128;    // double[4*4] per-wave double partials
 constexpr int SCR_FIT = 256;      // double[25] fit box values
@@ -228,7 +246,10 @@ SPX_DEVICE void block_sum2f(unsigned char* lds_scr, float& a, float& b) {
 SPX_DEVICE bool better(float v, int i, float bv, int bi) {
     return (v > bv) || (v == bv && i < bi);
 }
-SPX_DEVICE void block_argmax(unsigned char* lds_scr, float& v, int& idx, int slot = 0) {
+// `slot` (0/1) selects one of two scratch areas: consecutive calls alternate slots, and a
+// slot is only rewritten after at least one more workgroup barrier, so no trailing
+// barrier is needed.
+SPX_DEVICE void block_argmax(unsigned char* lds_scr, float& v, int& idx, int slot) {
     const int tid = rt::thread_id();
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -236,16 +257,14 @@ SPX_DEVICE void block_argmax(unsigned char* lds_scr, float& v, int& idx, int slo
         int oi = rt::shfl_xor(idx, m);
         if (better(ov, oi, v, idx)) { v = ov; idx = oi; }
     }
-    float* rf = reinterpret_cast<float*>(lds_scr + SCR_RED_F);
-    int* ri = reinterpret_cast<int*>(lds_scr + SCR_RED_I);
+    float* rf = reinterpret_cast<float*>(lds_scr + SCR_RED_F) + 8 * slot;
+    int* ri = reinterpret_cast<int*>(lds_scr + SCR_RED_F) + 8 * slot + 4;
     if ((tid & 63) == 0) { rf[tid >> 6] = v; ri[tid >> 6] = idx; }
     rt::block_sync_lds();
     v = rf[0];
     idx = ri[0];
     for (int w = 1; w < kThreads / 64; ++w)
         if (better(rf[w], ri[w], v, idx)) { v = rf[w]; idx = ri[w]; }
-    rt::block_sync_lds();
-    (void)slot;
 }
 
 // ---------------------------------------------------------------------------
@@ -494,19 +513,7 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk) {
     SPX_DBG_STOP(3);
     clk.tick(3);
     // ---- transposition: (lane (y0,x0), reg (kyb,kxb)) -> (lane (kyb,kxb), reg (y0,x0))
-#pragma unroll
-    for (int part = 0; part < 2; ++part) {
-#pragma unroll
-        for (int r = 0; r < 64; ++r)
-            xch[r * L::XS + lane] = part ? v[r >> 3][r & 7].y : v[r >> 3][r & 7].x;
-        rt::wave_sync();
-#pragma unroll
-        for (int r = 0; r < 64; ++r) {
-            const float t = xch[lane * L::XS + r];
-            if (part) v[r >> 3][r & 7].y = t; else v[r >> 3][r & 7].x = t;
-        }
-        rt::wave_sync();
-    }
+    transpose_tile<L::XS>(v, xch, lane);
 
     SPX_DBG_STOP(4);
     clk.tick(4);
@@ -545,19 +552,7 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk) {
     SPX_DBG_STOP(7);
     clk.tick(7);
     // ---- transposition back: -> lane (y0, x0), registers (kyb, kxb)
-#pragma unroll
-    for (int part = 0; part < 2; ++part) {
-#pragma unroll
-        for (int r = 0; r < 64; ++r)
-            xch[r * L::XS + lane] = part ? v[r >> 3][r & 7].y : v[r >> 3][r & 7].x;
-        rt::wave_sync();
-#pragma unroll
-        for (int r = 0; r < 64; ++r) {
-            const float t = xch[lane * L::XS + r];
-            if (part) v[r >> 3][r & 7].y = t; else v[r >> 3][r & 7].x = t;
-        }
-        rt::wave_sync();
-    }
+    transpose_tile<L::XS>(v, xch, lane);
     SPX_DBG_STOP(8);
     clk.tick(8);
     // ---- inverse round B': registers (kyb, kxb) -> (y1, x1)
@@ -692,8 +687,30 @@ SPX_DEVICE PeakResult peak_from_argmax(unsigned char* lds_scr, int imax, int jma
 // flipped coarse index (qyc, qxc),  F[b][a] = conv interpolated at q = U*qc + offset,
 // into fbuf[b*W + a] (first index = x offset).
 // ---------------------------------------------------------------------------
+// the lane-constant K operands of one wave (loaded early, under the coarse arg-max)
+template <int WB> struct FineTables {
+    f32x4 ky[WB][4], kx[WB][4];
+};
 template <int C, int WB>
-SPX_DEVICE void fine_window(unsigned char* lds, const float* __restrict__ ktab,
+SPX_DEVICE void load_fine_tables(FineTables<WB>& ft, const float* __restrict__ ktab) {
+    const int tid = fresh_tid();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int cy = wave / C, cx = wave % C;
+    ktab = rt::launder(ktab);
+    // table slices of this lane: [2 (y|x)][2 (class)][WB][64 lanes][16]
+    const f32x4* kty = reinterpret_cast<const f32x4*>(ktab) + ((size_t)(0 * 2 + cy) * WB * 64 + lane) * 4;
+    const f32x4* ktx = reinterpret_cast<const f32x4*>(ktab) + ((size_t)(1 * 2 + cx) * WB * 64 + lane) * 4;
+#pragma unroll
+    for (int b = 0; b < WB; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ft.ky[b][i] = kty[b * 64 * 4 + i];
+            ft.kx[b][i] = ktx[b * 64 * 4 + i];
+        }
+}
+
+template <int C, int WB>
+SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB>& ft,
                             int ny, int nx, int qyc, int qxc) {
     typedef Lds<C> L;
     static_assert(C == 2, "");
@@ -705,10 +722,6 @@ SPX_DEVICE void fine_window(unsigned char* lds, const float* __restrict__ ktab,
     const float* plane = reinterpret_cast<const float*>(lds + L::R_OFF + wave * L::PLANE_STRIDE_BYTES);
     float* fbuf = reinterpret_cast<float*>(lds + L::FB_OFF);
     const int lyc = conv_index(ny, qyc), lxc = conv_index(nx, qxc);
-    // table slices of this lane: [2 (y|x)][2 (class)][WB][64 lanes][16]
-    ktab = rt::launder(ktab);
-    const f32x4* kty = reinterpret_cast<const f32x4*>(ktab) + ((size_t)(0 * 2 + cy) * WB * 64 + lane) * 4;
-    const f32x4* ktx = reinterpret_cast<const f32x4*>(ktab) + ((size_t)(1 * 2 + cx) * WB * 64 + lane) * 4;
 
     // d_c[m] = (-1)^(c floor(m/64)) plane[m mod 64]: the sign of a wrapped row goes
     // into the K operand of that row, the sign of a wrapped column likewise.
@@ -726,7 +739,7 @@ SPX_DEVICE void fine_window(unsigned char* lds, const float* __restrict__ ktab,
     for (int s4 = 0; s4 < 4; ++s4) {
         f32x4 kb[WB];
 #pragma unroll
-        for (int ab = 0; ab < WB; ++ab) kb[ab] = kty[ab * 64 * 4 + s4];
+        for (int ab = 0; ab < WB; ++ab) kb[ab] = ft.ky[ab][s4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int step = 4 * s4 + e;
@@ -753,7 +766,7 @@ SPX_DEVICE void fine_window(unsigned char* lds, const float* __restrict__ ktab,
     for (int t = 0; t < 4; ++t) {
         f32x4 ka[WB];
 #pragma unroll
-        for (int bb = 0; bb < WB; ++bb) ka[bb] = ktx[bb * 64 * 4 + t];
+        for (int bb = 0; bb < WB; ++bb) ka[bb] = ft.kx[bb][t];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = lxc + 16 * t + 4 * lk + r - 32;
@@ -912,11 +925,14 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
     // pull the next pair into L2 while this one is in its tail
     if (next_ref) warm = warm_next_pair(next_ref, next_img);
 
+    // the refine stage's constant operands: issue the loads now, use them after the arg-max
+    FineTables<(WB > 0 ? WB : 1)> ft;
+    if constexpr (WB > 0) load_fine_tables<C, WB>(ft, ktab);
     // coarse arg-max over the flipped 'same' window (centroid.py:114-116)
     float bv;
     int bi;
     coarse_argmax<C>(lds, ny, nx, oscale, bv, bi);
-    block_argmax(scr, bv, bi);
+    block_argmax(scr, bv, bi, 0);
     int qyc = bi / nx, qxc = bi - (bi / nx) * nx;
     clk.tick(11);
     if constexpr (DBG == 11) { if (tid == 0) out[0] = (double)bi; return; }
@@ -932,7 +948,7 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
         int imax = 0, jmax = 0;
         bool inside = false;
         for (int iter = 0; iter < 4; ++iter) {
-            fine_window<C, (WB > 0 ? WB : 1)>(lds, ktab, ny, nx, qyc, qxc);
+            fine_window<C, (WB > 0 ? WB : 1)>(lds, ft, ny, nx, qyc, qxc);
             clk.tick(12);
             if constexpr (DBG == 12) { if (tid == 0) out[0] = (double)fine_value<C, W>(lds, 0, 0); return; }
             // arg-max over the part of the window inside the virtual image
@@ -947,7 +963,7 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
                     if (better(val, idx, fv, fi)) { fv = val; fi = idx; }
                 }
             }
-            block_argmax(scr, fv, fi);
+            block_argmax(scr, fv, fi, 1);
             clk.tick(13);
             if constexpr (DBG == 13) { if (tid == 0) out[0] = (double)fi; return; }
             const int a = fi / W, b = fi % W;
@@ -1052,7 +1068,7 @@ SPX_DEVICE void disp5_body(const float* __restrict__ ref, const float* __restric
         rt::block_sync_lds();                    // planes are overwritten by the next stage
     }
     rt::block_sync();        // icc (GLOBAL memory) written above is read below by other waves
-    block_argmax(scr, bv, bi);
+    block_argmax(scr, bv, bi, 0);
     const int jmax = bi / NX, imax = bi % NX;
     PeakResult pk = peak_from_argmax(scr, imax, jmax, NX, NY, [&](int x, int y) {
         return icc[y * NX + x];

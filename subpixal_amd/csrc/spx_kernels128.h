@@ -1,0 +1,505 @@
+// spx_kernels128.h -- the 128x128 tile (cutouts of 65..128 pixels per side;
+// BASELINE.json config 3): same path as spx_kernels.h, FFT period P = 256.
+//
+// The padded spectrum splits into 16 classes  Z[4k'+c] = FFT64{ fold_c(z)[x'] w_P^(c x') },
+// fold_c(z)[x'] = z[x'] + (-i)^c z[x'+64]  (per axis), each again a 64x64 complex FFT done
+// by one wave in registers with the machinery of spx_kernels.h.  A workgroup (4 waves) runs
+// 4 rounds of 4 classes.  128x128 does not fit the LDS the way 64x64 does ("stresses LDS tile
+// sizing"), so the per-class results  g_c[l'] = sum_{k in c} Z[k]^2 e^{2 pi i k l'/P}  (complex,
+// 64x64) go to a per-workgroup workspace that stays in L2/MALL, a radix-4 pass combines them into
+// the full 256x256 real convolution  conv[l'+64s] = Im( sum_c i^(c.s) g_c[l'] ) / 2P^2  there, and
+// the arg-max, the MFMA refine (period-256 Dirichlet kernel, real) and the fit read from it.
+//
+// Workspace per workgroup: 16 x 2 planes of 64x64 floats (512 KiB) + 256x256 floats (256 KiB).
+#pragma once
+
+namespace spx {
+
+struct Lds128 {
+    static constexpr int P = 256;
+    static constexpr int ZS = 72, XS = 68;
+    static constexpr int TW_OFF = 0;                       // cf[256]
+    static constexpr int SCR_OFF = TW_OFF + P * 8;         // 1 KiB scratch
+    static constexpr int R_OFF = SCR_OFF + 1024;
+    static constexpr int ZBUF_BYTES = 2 * 64 * ZS * 4;
+    static constexpr int XCH_WAVE_BYTES = 64 * XS * 4;
+    static constexpr int XCH_BYTES = 4 * XCH_WAVE_BYTES;
+    static constexpr int FB_OFF = R_OFF + XCH_BYTES;       // 4 per-wave fine windows
+    static constexpr int total(int W) { return FB_OFF + 4 * W * W * 4; }
+};
+constexpr size_t kWs128PlaneFloats = 64 * 64;
+constexpr size_t kWs128Bytes = (size_t)(16 * 2 * 64 * 64 + 256 * 256) * sizeof(float);
+
+// one 64x64 quadrant block (sy, sx) of z = ref + i*bal*flip(img), normalised, into LDS
+SPX_DEVICE void stage_block128(unsigned char* lds, const float* __restrict__ ref,
+                               const float* __restrict__ img, int ny, int nx, int sy, int sx,
+                               const NormStats& ns, float bal) {
+    typedef Lds128 L;
+    const int tid = fresh_tid();
+    float* zre = reinterpret_cast<float*>(lds + L::R_OFF);
+    float* zim = zre + 64 * L::ZS;
+    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
+        const int yl = idx >> 6, xl = idx & 63;
+        const int y = yl + 64 * sy, x = xl + 64 * sx;
+        float r = 0.0f, m = 0.0f;
+        if (y < ny && x < nx) {
+            r = ref[(int64_t)y * nx + x];
+            m = img[(int64_t)(ny - 1 - y) * nx + (nx - 1 - x)];     // flipped: cc.py:114
+            if (ns.active) {
+                if (m != 0.0f) { m = m - ns.im_mean; m = m / ns.im_std; }
+                r = r - ns.ref_mean;
+                r = r / ns.ref_std;
+            }
+            m *= bal;
+        }
+        zre[yl * L::ZS + xl] = r;
+        zim[yl * L::ZS + xl] = m;
+    }
+}
+
+// sum ref^2 and sum img^2 over the cutout (after normalisation) -> balance factor
+SPX_DEVICE float balance128(unsigned char* scr, const float* __restrict__ ref,
+                            const float* __restrict__ img, int ny, int nx, const NormStats& ns) {
+    const int tid = fresh_tid();
+    float ssq[2] = {0.0f, 0.0f};
+    for (int i = tid; i < ny * nx; i += kThreads) {
+        float r = ref[i], m = img[i];
+        if (ns.active) {
+            if (m != 0.0f) m = (m - ns.im_mean) / ns.im_std;
+            r = (r - ns.ref_mean) / ns.ref_std;
+        }
+        ssq[0] += r * r;
+        ssq[1] += m * m;
+    }
+    return balance_factor(scr, ssq);
+}
+
+// One round: classes (cy, cx = wave) of the staged pair -> complex planes in the workspace.
+SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref,
+                               const float* __restrict__ img, int ny, int nx, const NormStats& ns,
+                               float bal, int cy, float* __restrict__ ws) {
+    typedef Lds128 L;
+    const int tid = fresh_tid();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int cx = wave;
+    const int l1 = lane >> 3, l0 = lane & 7;
+    const cf* tw = reinterpret_cast<const cf*>(lds + L::TW_OFF);
+    const float* zre = reinterpret_cast<const float*>(lds + L::R_OFF);
+    const float* zim = zre + 64 * L::ZS;
+    float* xch = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::XCH_WAVE_BYTES);
+
+    rt::block_sync_lds();      // the previous round's exchange buffers alias the staging area
+    cf v[8][8];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) v[r >> 3][r & 7] = cf{0.0f, 0.0f};
+    // fold the four quadrant blocks: v += (-i)^(cy sy + cx sx) z[y'+64 sy][x'+64 sx]
+    for (int s = 0; s < 4; ++s) {
+        const int sy = s >> 1, sx = s & 1;
+        const bool any = (64 * sy < ny) && (64 * sx < nx);      // block not entirely padding
+        if (any) stage_block128(lds, ref, img, ny, nx, sy, sx, ns, bal);
+        rt::block_sync_lds();
+        if (any) {
+            const int m = (cy * sy + cx * sx) & 3;
+#pragma unroll
+            for (int y1 = 0; y1 < 8; ++y1)
+#pragma unroll
+                for (int x1 = 0; x1 < 8; ++x1) {
+                    const int a = (l1 + 8 * y1) * L::ZS + l0 + 8 * x1;
+                    const cf t = cf{zre[a], zim[a]};
+                    cf& d = v[y1][x1];
+                    if (m == 0) d = d + t;
+                    else if (m == 1) d = rt::add_mi(d, t);
+                    else if (m == 2) d = d - t;
+                    else d = rt::add_pi(d, t);
+                }
+        }
+        rt::block_sync_lds();
+    }
+    // class pre-twiddle w_P^{c (8 y1)}
+    if (cy) {
+#pragma unroll
+        for (int y1 = 1; y1 < 8; ++y1) {
+            const cf w = tw[8 * cy * y1];
+#pragma unroll
+            for (int x1 = 0; x1 < 8; ++x1) v[y1][x1] = cmul(v[y1][x1], w);
+        }
+    }
+    if (cx) {
+#pragma unroll
+        for (int x1 = 1; x1 < 8; ++x1) {
+            const cf w = tw[8 * cx * x1];
+#pragma unroll
+            for (int y1 = 0; y1 < 8; ++y1) v[y1][x1] = cmul(v[y1][x1], w);
+        }
+    }
+    fft8_y<1>(v);
+    fft8_x<1>(v);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const cf wy = tw[l1 * (cy + 4 * kb)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[kb][j] = cmul(v[kb][j], wy);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const cf wx = tw[l0 * (cx + 4 * kb)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j][kb] = cmul(v[j][kb], wx);
+    }
+    transpose_tile<L::XS>(v, xch, lane);
+    fft8_y<1>(v);
+    fft8_x<1>(v);
+#pragma unroll
+    for (int r = 0; r < 64; ++r) v[r >> 3][r & 7] = cmul(v[r >> 3][r & 7], v[r >> 3][r & 7]);
+    fft8_y<-1>(v);
+    fft8_x<-1>(v);
+#pragma unroll
+    for (int y0 = 0; y0 < 8; ++y0) {
+        const cf wy = tw[y0 * (cy + 4 * l1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[y0][j] = cmulc(v[y0][j], wy);
+    }
+#pragma unroll
+    for (int x0 = 0; x0 < 8; ++x0) {
+        const cf wx = tw[x0 * (cx + 4 * l0)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j][x0] = cmulc(v[j][x0], wx);
+    }
+    transpose_tile<L::XS>(v, xch, lane);
+    fft8_y<-1>(v);
+    fft8_x<-1>(v);
+    // class post-twiddle conj(w_P^{8 (cy y1 + cx x1)})
+#pragma unroll
+    for (int y1 = 0; y1 < 8; ++y1) {
+        const cf wy = tw[8 * cy * y1];
+#pragma unroll
+        for (int x1 = 0; x1 < 8; ++x1) {
+            const cf wx = tw[8 * cx * x1];
+            v[y1][x1] = cmulc(cmulc(v[y1][x1], wy), wx);
+        }
+    }
+    // g_c -> workspace planes [class][re|im][64][64], through the wave's LDS buffer so the
+    // global stores are 16-byte, row-contiguous
+    float* g = ws + (size_t)((cy * 4 + cx) * 2) * kWs128PlaneFloats;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int y1 = 0; y1 < 8; ++y1)
+#pragma unroll
+            for (int x1 = 0; x1 < 8; ++x1)
+                xch[(l1 + 8 * y1) * 64 + l0 + 8 * x1] = part ? v[y1][x1].y : v[y1][x1].x;
+        rt::wave_sync();
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            reinterpret_cast<f32x4*>(g + part * kWs128PlaneFloats)[i * 64 + lane] =
+                reinterpret_cast<const f32x4*>(xch)[i * 64 + lane];
+        rt::wave_sync();
+    }
+}
+
+// radix-4 combination of the 16 class planes into the full real convolution:
+// conv[l'+64 s] = out_scale * Im( sum_c i^(cy sy + cx sx) g_c[l'] )
+SPX_DEVICE void combine128(const float* __restrict__ ws, float* __restrict__ conv, float out_scale) {
+    const int tid = fresh_tid();
+    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
+        cf g[4][4];
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            g[c >> 2][c & 3] = cf{ws[(size_t)(c * 2) * kWs128PlaneFloats + idx],
+                                  ws[(size_t)(c * 2 + 1) * kWs128PlaneFloats + idx]};
+        // DFT-4 with +i along cx, then along cy:  X[s] = sum_c i^(c s) a[c]
+        cf h[4][4];
+#pragma unroll
+        for (int cy = 0; cy < 4; ++cy) {
+            const cf a0 = g[cy][0], a1 = g[cy][1], a2 = g[cy][2], a3 = g[cy][3];
+            const cf e0 = a0 + a2, e1 = a0 - a2, o0 = a1 + a3, o1 = a1 - a3;
+            h[cy][0] = e0 + o0;
+            h[cy][2] = e0 - o0;
+            h[cy][1] = rt::add_pi(e1, o1);      // e1 + i o1
+            h[cy][3] = rt::add_mi(e1, o1);      // e1 - i o1
+        }
+        const int ly = idx >> 6, lx = idx & 63;
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) {
+            const cf a0 = h[0][sx], a1 = h[1][sx], a2 = h[2][sx], a3 = h[3][sx];
+            const cf e0 = a0 + a2, e1 = a0 - a2, o0 = a1 + a3, o1 = a1 - a3;
+            const cf x0 = e0 + o0, x2 = e0 - o0, x1 = rt::add_pi(e1, o1), x3 = rt::add_mi(e1, o1);
+            conv[(size_t)(ly + 0) * 256 + lx + 64 * sx] = out_scale * x0.y;
+            conv[(size_t)(ly + 64) * 256 + lx + 64 * sx] = out_scale * x1.y;
+            conv[(size_t)(ly + 128) * 256 + lx + 64 * sx] = out_scale * x2.y;
+            conv[(size_t)(ly + 192) * 256 + lx + 64 * sx] = out_scale * x3.y;
+        }
+    }
+}
+
+// cutout pair -> full 256x256 convolution in the workspace (ends with a full barrier)
+SPX_DEVICE void conv_full128(unsigned char* lds, const float* __restrict__ ref,
+                             const float* __restrict__ img, int ny, int nx, const NormStats& ns,
+                             float* __restrict__ ws) {
+    typedef Lds128 L;
+    unsigned char* scr = lds + L::SCR_OFF;
+    const float bal = balance128(scr, ref, img, ny, nx, ns);
+    for (int cy = 0; cy < 4; ++cy) class_round128(lds, ref, img, ny, nx, ns, bal, cy, ws);
+    rt::block_sync();                    // class planes (global) visible to every wave
+    // conv = Im(IFFT(Z^2)) / 2, IFFT normalisation 1/P^2, balance undone
+    const float out_scale = 0.5f / ((float)(L::P) * (float)(L::P) * bal);
+    combine128(ws, ws + 32 * kWs128PlaneFloats, out_scale);
+    rt::block_sync();
+}
+
+SPX_DEVICE float window_value128(const float* __restrict__ conv, int ny, int nx, int qy, int qx) {
+    return conv[(size_t)conv_index(ny, qy) * 256 + conv_index(nx, qx)];
+}
+
+// coarse arg-max over the flipped 'same' window (cutouts up to 128x128)
+SPX_DEVICE void coarse_argmax128(const float* __restrict__ conv, int ny, int nx, float& bv, int& bi) {
+    const int tid = fresh_tid();
+    bv = -__builtin_inff();
+    bi = 0x7fffffff;
+    const int qx = tid & 127;
+    if (qx < nx) {
+        for (int qy = tid >> 7; qy < ny; qy += kThreads / 128) {
+            const float val = window_value128(conv, ny, nx, qy, qx);
+            const int idx = qy * nx + qx;
+            if (better(val, idx, bv, bi)) { bv = val; bi = idx; }
+        }
+    }
+}
+
+// Fine window around flipped coarse index (qyc, qxc) by MFMA, period-256 real kernel
+//   K(t) = 1/256 [1 + 2 sum_{j=1..127} cos(2 pi j t / 256) + cos(pi t)].
+// Tables (spx_tables.h make_ktab256), lane = 16 lk + lj:
+//   [0][blk][lane][s]       = K(-(16 blk + lj - W/2)/U - (4 s + lk - 128)),      s in [0,64)
+//   [1][blk][lane][4 t + r] = K(-(16 blk + lj - W/2)/U - (16 t + 4 lk + r - 128)), t in [0,16)
+// Wave w contracts all 256 rows for its 4 column tiles t = 4w..4w+3 and leaves its partial
+// window in its own LDS buffer; the reader adds the four (fine_value128).
+template <int WB>
+SPX_DEVICE void fine_window128(unsigned char* lds, const float* __restrict__ ktab,
+                               const float* __restrict__ conv, int ny, int nx, int qyc, int qxc) {
+    typedef Lds128 L;
+    constexpr int W = 16 * WB;
+    const int tid = fresh_tid();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lk = lane >> 4, lj = lane & 15;
+    float* fbuf = reinterpret_cast<float*>(lds + L::FB_OFF) + wave * W * W;
+    const int lyc = conv_index(ny, qyc), lxc = conv_index(nx, qxc);
+    ktab = rt::launder(ktab);
+    const f32x4* kty = reinterpret_cast<const f32x4*>(ktab) + (size_t)lane * 16;
+    const f32x4* ktx = reinterpret_cast<const f32x4*>(ktab) + (size_t)(WB * 64 + lane) * 16;
+
+    f32x4 acc[WB][4];
+#pragma unroll
+    for (int ab = 0; ab < WB; ++ab)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[ab][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int col[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) col[t] = (lxc + 16 * (4 * wave + t) + lj - 128) & 255;
+    for (int s4 = 0; s4 < 16; ++s4) {
+        f32x4 kb[WB];
+#pragma unroll
+        for (int ab = 0; ab < WB; ++ab) kb[ab] = kty[(size_t)ab * 64 * 16 + s4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = (lyc + 4 * (4 * s4 + e) + lk - 128) & 255;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float afrag = conv[(size_t)row * 256 + col[t]];
+#pragma unroll
+                for (int ab = 0; ab < WB; ++ab)
+                    acc[ab][t] = rt::mfma_16x16x4(afrag, kb[ab][e], acc[ab][t]);
+            }
+        }
+    }
+    f32x4 f[WB][WB];
+#pragma unroll
+    for (int bb = 0; bb < WB; ++bb)
+#pragma unroll
+        for (int ab = 0; ab < WB; ++ab) f[bb][ab] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x4 ka[WB];
+#pragma unroll
+        for (int bb = 0; bb < WB; ++bb) ka[bb] = ktx[(size_t)bb * 64 * 16 + 4 * wave + t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int bb = 0; bb < WB; ++bb)
+#pragma unroll
+                for (int ab = 0; ab < WB; ++ab)
+                    f[bb][ab] = rt::mfma_16x16x4(ka[bb][r], acc[ab][t][r], f[bb][ab]);
+    }
+#pragma unroll
+    for (int bb = 0; bb < WB; ++bb)
+#pragma unroll
+        for (int ab = 0; ab < WB; ++ab)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                fbuf[(bb * 16 + 4 * lk + r) * W + ab * 16 + lj] = f[bb][ab][r];
+    rt::block_sync_lds();
+}
+
+template <int W> SPX_DEVICE float fine_value128(const unsigned char* lds, int b, int a) {
+    const float* fbuf = reinterpret_cast<const float*>(lds + Lds128::FB_OFF);
+    float acc = fbuf[b * W + a];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) acc += fbuf[w * W * W + b * W + a];
+    return acc;
+}
+
+// ---------------------------------------------------------------------------
+// pair mode, 128 tile
+// ---------------------------------------------------------------------------
+template <int WB>
+SPX_DEVICE void pair128_body(const float* __restrict__ ref, const float* __restrict__ img, int ny,
+                             int nx, int U, int cc_type, const float* __restrict__ ktab,
+                             double* __restrict__ out, int* __restrict__ status,
+                             unsigned char* lds, float* __restrict__ ws) {
+    typedef Lds128 L;
+    ny = rt::launder_uniform(ny);
+    nx = rt::launder_uniform(nx);
+    U = rt::launder_uniform(U);
+    const int tid = fresh_tid();
+    unsigned char* scr = lds + L::SCR_OFF;
+    const NormStats ns = norm_stats(scr, ref, img, 1, 0, ny, nx, cc_type);
+    conv_full128(lds, ref, img, ny, nx, ns, ws);
+    const float* conv = ws + 32 * kWs128PlaneFloats;
+
+    float bv;
+    int bi;
+    coarse_argmax128(conv, ny, nx, bv, bi);
+    block_argmax(scr, bv, bi, 0);
+    int qyc = bi / nx, qxc = bi - (bi / nx) * nx;
+    PeakResult pk;
+    if constexpr (WB == 0) {
+        pk = peak_fit_wave0(scr, qxc, qyc, nx, ny, [&](int x, int y) {
+            return window_value128(conv, ny, nx, y, x);
+        });
+    } else {
+        constexpr int W = 16 * (WB > 0 ? WB : 1);
+        const int NX = U * nx, NY = U * ny;
+        int imax = 0, jmax = 0;
+        bool inside = false;
+        for (int iter = 0; iter < 4; ++iter) {
+            fine_window128<(WB > 0 ? WB : 1)>(lds, ktab, conv, ny, nx, qyc, qxc);
+            const int fx0 = U * qxc - W / 2, fy0 = U * qyc - W / 2;
+            float fv = -__builtin_inff();
+            int fi = 0x7fffffff;
+            for (int idx = tid; idx < W * W; idx += kThreads) {
+                const int a = idx / W, b = idx % W;
+                const int gy = fy0 + a, gx = fx0 + b;
+                if (gy >= 0 && gy < NY && gx >= 0 && gx < NX) {
+                    const float val = fine_value128<W>(lds, b, a);
+                    if (better(val, idx, fv, fi)) { fv = val; fi = idx; }
+                }
+            }
+            block_argmax(scr, fv, fi, 1);
+            const int a = fi / W, b = fi % W;
+            jmax = fy0 + a;
+            imax = fx0 + b;
+            int x1 = imax - 2, y1 = jmax - 2;
+            if (x1 > NX - 5) x1 = NX - 5;
+            if (y1 > NY - 5) y1 = NY - 5;
+            if (x1 < 0) x1 = 0;
+            if (y1 < 0) y1 = 0;
+            const bool okx = (x1 >= fx0 && x1 + 4 < fx0 + W) || imax == 0;
+            const bool oky = (y1 >= fy0 && y1 + 4 < fy0 + W) || jmax == 0;
+            if (okx && oky) { inside = true; break; }
+            if (!okx) qxc += (b < W / 2) ? -1 : 1;
+            if (!oky) qyc += (a < W / 2) ? -1 : 1;
+            qxc = qxc < 0 ? 0 : (qxc > nx - 1 ? nx - 1 : qxc);
+            qyc = qyc < 0 ? 0 : (qyc > ny - 1 ? ny - 1 : qyc);
+            rt::block_sync_lds();       // everyone has read the window before it is rebuilt
+        }
+        if (inside) {
+            const int fx0 = U * qxc - W / 2, fy0 = U * qyc - W / 2;
+            pk = peak_fit_wave0(scr, imax, jmax, NX, NY, [&](int x, int y) {
+                return fine_value128<W>(lds, x - fx0, y - fy0);
+            });
+        } else {
+            pk.x = (double)imax; pk.y = (double)jmax; pk.status = ST_WINDOW;
+        }
+    }
+    if (tid == 0) {
+        out[0] = pk.x / (double)U - (double)((nx - 1) / 2);
+        out[1] = pk.y / (double)U - (double)((ny - 1) / 2);
+        if (status) status[0] = pk.status;
+    }
+}
+
+SPX_DEVICE void load_twiddles128(unsigned char* lds, const cf* __restrict__ tw_g) {
+    cf* tw = reinterpret_cast<cf*>(lds + Lds128::TW_OFF);
+    for (int i = rt::thread_id(); i < Lds128::P; i += kThreads) tw[i] = tw_g[i];
+    rt::block_sync_lds();
+}
+
+template <int WB>
+SPX_TKERNEL(256) void pair128_kernel(const float* __restrict__ ref, const float* __restrict__ img,
+                                     int64_t nbatch, int ny, int nx, int U, int cc_type,
+                                     const cf* __restrict__ tw_g, const float* __restrict__ ktab,
+                                     double* __restrict__ out, int* __restrict__ status,
+                                     float* __restrict__ workspace) {
+    SPX_DYN_LDS(lds);
+    load_twiddles128(lds, tw_g);
+    float* ws = workspace + (size_t)rt::block_id() * (kWs128Bytes / sizeof(float));
+    const int64_t stride = (int64_t)ny * nx;
+    for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
+        pair128_body<WB>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, ktab, out + 2 * p,
+                         status ? status + p : nullptr, lds, ws);
+        rt::block_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// reference (5-image) mode, 128 tile
+// ---------------------------------------------------------------------------
+SPX_TKERNEL(256) void disp5_128_kernel(const float* __restrict__ ref, const float* __restrict__ im4,
+                                       int64_t nbatch, int ny, int nx, int cc_type,
+                                       const cf* __restrict__ tw_g, float* __restrict__ icc_all,
+                                       double* __restrict__ out_all, int* __restrict__ status,
+                                       float* __restrict__ workspace) {
+    typedef Lds128 L;
+    SPX_DYN_LDS(lds);
+    load_twiddles128(lds, tw_g);
+    float* ws = workspace + (size_t)rt::block_id() * (kWs128Bytes / sizeof(float));
+    const float* conv = ws + 32 * kWs128PlaneFloats;
+    unsigned char* scr = lds + L::SCR_OFF;
+    const int64_t stride = (int64_t)ny * nx;
+    const int NX = 2 * nx, NY = 2 * ny;
+    for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
+        const float* r = ref + p * stride;
+        const float* m4 = im4 + 4 * p * stride;
+        float* icc = icc_all + 4 * p * stride;
+        const int tid = fresh_tid();
+        const NormStats ns = norm_stats(scr, r, m4, 4, stride, ny, nx, cc_type);
+        float bv = -__builtin_inff();
+        int bi = 0x7fffffff;
+        for (int q = 0; q < 4; ++q) {
+            const int ox = q & 1, oy = q >> 1;
+            conv_full128(lds, r, m4 + q * stride, ny, nx, ns, ws);
+            const int qx = tid & 127;
+            if (qx < nx) {
+                for (int qy = tid >> 7; qy < ny; qy += kThreads / 128) {
+                    const float val = window_value128(conv, ny, nx, qy, qx);
+                    const int gi = (2 * qy + oy) * NX + 2 * qx + ox;
+                    icc[gi] = val;
+                    if (better(val, gi, bv, bi)) { bv = val; bi = gi; }
+                }
+            }
+            rt::block_sync();
+        }
+        block_argmax(scr, bv, bi, 0);
+        const int jmax = bi / NX, imax = bi % NX;
+        PeakResult pk = peak_fit_wave0(scr, imax, jmax, NX, NY, [&](int x, int y) {
+            return icc[(size_t)y * NX + x];
+        });
+        if (tid == 0) {
+            out_all[2 * p] = 0.5 * pk.x - (double)((NX - 1) / 4);
+            out_all[2 * p + 1] = 0.5 * pk.y - (double)((NY - 1) / 4);
+            if (status) status[p] = pk.status;
+        }
+        rt::block_sync();
+    }
+}
+
+}  // namespace spx

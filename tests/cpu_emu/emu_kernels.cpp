@@ -3,6 +3,7 @@
 #include "spx_rt_emu.h"
 #include "spx_kernels.h"
 #include "spx_aux_kernels.h"
+#include "spx_kernels128.h"
 #include "spx_tables.h"
 
 using namespace spx;
@@ -70,6 +71,43 @@ extern "C" int emu_gen_pairs(uint64_t seed, int64_t first, int64_t nbatch, int n
                              float shi, float maxshift, float* ref, float* img, double* truth) {
     rt::launch(nbatch, 256, [&] {
         gen_pairs_kernel(seed, first, nbatch, n, slo, shi, maxshift, ref, img, truth);
+    });
+    return 0;
+}
+
+extern "C" int emu_pair128(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
+                           int U, int cc_type, double* out, int* status) {
+    if (ny < 5 || nx < 5 || ny > 128 || nx > 128) return -1;
+    const int wb = host::window_blocks(U);
+    if (wb < 0) return -2;
+    std::vector<float> tw = host::make_twiddles(256);
+    std::vector<float> kt;
+    if (wb > 0) kt = host::make_ktab256(U, 16 * wb);
+    const cf* twp = reinterpret_cast<const cf*>(tw.data());
+    const float* ktp = kt.empty() ? nullptr : kt.data();
+    const int64_t grid = g_grid > 0 && g_grid < nbatch ? g_grid : nbatch;
+    std::vector<float> ws((size_t)grid * (kWs128Bytes / sizeof(float)));
+    float* wsp = ws.data();
+    auto run = [&](auto fn) { rt::launch(grid, kThreads, fn); };
+    switch (wb) {
+    case 0: run([&] { pair128_kernel<0>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    case 1: run([&] { pair128_kernel<1>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    case 2: run([&] { pair128_kernel<2>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    case 3: run([&] { pair128_kernel<3>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    default: run([&] { pair128_kernel<4>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    }
+    return 0;
+}
+
+extern "C" int emu_disp5_128(const float* ref, const float* im4, int64_t nbatch, int ny, int nx,
+                             int cc_type, float* icc, double* out, int* status) {
+    if (ny < 3 || nx < 3 || ny > 128 || nx > 128) return -1;
+    std::vector<float> tw = host::make_twiddles(256);
+    const cf* twp = reinterpret_cast<const cf*>(tw.data());
+    std::vector<float> ws((size_t)nbatch * (kWs128Bytes / sizeof(float)));
+    float* wsp = ws.data();
+    rt::launch(nbatch, kThreads, [&] {
+        disp5_128_kernel(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, wsp);
     });
     return 0;
 }

@@ -34,19 +34,23 @@ def test_library_exports_every_declared_symbol():
 def test_argument_errors_without_gpu():
     from subpixal_amd import _ffi
     lib = _ffi.load()
-    assert lib.spx_workspace_bytes_displacement5(10, 64, 64) == 10 * 4 * 64 * 64 * 4
+    assert lib.spx_workspace_bytes_displacement5(10, 64, 64, 1) == 10 * 4 * 64 * 64 * 4
+    assert lib.spx_workspace_bytes_displacement5(10, 64, 64, 0) == 0
+    assert lib.spx_workspace_bytes_xcorr(10, 64, 64) == 0
+    assert lib.spx_workspace_bytes_xcorr(10, 65, 64) == 10 * 768 * 1024
     # argument validation happens before any HIP call
-    assert lib.spx_xcorr_refine_f32(None, None, 1, 64, 64, 1, 0, None, None, None) == -1
-    assert lib.spx_xcorr_refine_f32(None, None, 0, 64, 64, 1, 0, None, None, None) == 0
-    assert lib.spx_xcorr_refine_f32(None, None, -1, 64, 64, 1, 0, None, None, None) == -1
+    assert lib.spx_xcorr_refine_f32(None, None, 1, 64, 64, 1, 0, None, None, None, 0, None) == -1
+    assert lib.spx_xcorr_refine_f32(None, None, 0, 64, 64, 1, 0, None, None, None, 0, None) == 0
+    assert lib.spx_xcorr_refine_f32(None, None, -1, 64, 64, 1, 0, None, None, None, 0, None) == -1
     buf = (ctypes.c_double * 4)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert lib.spx_xcorr_refine_f32(p, p, 1, 65, 64, 1, 0, p, None, None) == -2
-    assert b'5..64' in lib.spx_last_error()
-    assert lib.spx_xcorr_refine_f32(p, p, 1, 64, 64, 60, 0, p, None, None) == -2
-    assert lib.spx_find_displacement5_f32(p, p, 1, 64, 64, 0, p, None, None, None, 0, None) == -4
+    assert lib.spx_xcorr_refine_f32(p, p, 1, 129, 64, 1, 0, p, None, None, 0, None) == -2
+    assert b'5..128' in lib.spx_last_error()
+    assert lib.spx_xcorr_refine_f32(p, p, 1, 65, 64, 1, 0, p, None, None, 0, None) == -4     # 128 tile needs workspace
+    assert lib.spx_xcorr_refine_f32(p, p, 1, 64, 64, 60, 0, p, None, None, 0, None) == -2
+    assert lib.spx_find_displacement5_f32(p, p, 1, 128, 128, 0, p, None, p, None, 0, None) == -4
     assert lib.spx_find_peak_f64(p, None, None, 1, 8, 8, 0, 5, 0, 0, p, None, None) == -1
-    assert lib.spx_xcorr_refine_f32(p, p, 0, 64, 64, 1, 0, p, None, None) == 0   # empty batch
+    assert lib.spx_xcorr_refine_f32(p, p, 0, 64, 64, 1, 0, p, None, None, 0, None) == 0   # empty batch
 
 
 def test_python_api_errors_mirror_reference():

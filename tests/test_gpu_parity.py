@@ -42,9 +42,22 @@ def test_pair_mode_vs_oracle_n64(spx, up, tol):
         assert np.max(np.abs(got - truth)) < 1e-3
 
 
+@pytest.mark.parametrize('up,tol', [(1, 1e-5), (2, 2e-5), (20, 5e-4)])   # float32 noise on the 20x finer grid
+def test_pair_mode_vs_oracle_n128(spx, up, tol):
+    """BASELINE config 3 shape: 128x128 cutouts (FFT period 256, 16 spectral classes,
+    L2-resident workspace), upsample=20."""
+    ref, img, truth = datagen.pair_batch(31, 8, 128)
+    got, st = spx.xcorr_refine_batch(ref, img, upsample=up, return_status=True)
+    exp, est = orc.xcorr_refine_batch(ref, img, up)
+    assert np.max(np.abs(got - exp)) < tol
+    assert np.array_equal(st, est)
+    if up >= 10:
+        assert np.max(np.abs(got - truth)) < 1e-3
+
+
 def test_pair_mode_u1_vs_reference_goldens(spx, golden_dir):
     g = _load(golden_dir, 'pair_u1.npz')
-    for n in (32, 33, 64):
+    for n in (32, 33, 64, 128):
         sel = np.where((g['n'] == n))[0]
         ref = np.empty((len(sel), n, n), np.float32)
         img = np.empty_like(ref)
@@ -62,7 +75,7 @@ def test_pair_mode_vs_reference_5image_path(spx, golden_dir):
     Gaussian-spot cutouts (sigma >= 4 px at n = 64); U=2 is the reference's own
     half-pixel interlace and agrees far better."""
     g = _load(golden_dir, 'bench_parity.npz')
-    for n, up, tol in ((64, 2, 2e-5), (64, 10, 1e-3), (32, 2, 1e-4)):
+    for n, up, tol in ((64, 2, 2e-5), (64, 10, 1e-3), (32, 2, 1e-4), (128, 2, 2e-5), (128, 20, 1e-3)):
         p = g['n%d_params' % n]
         exp = g['n%d_dxdy' % n]
         ref = np.empty((len(p), n, n), np.float32)
@@ -75,7 +88,8 @@ def test_pair_mode_vs_reference_5image_path(spx, golden_dir):
 
 def test_pair_mode_shapes_cc_types_and_zeros(spx):
     rng = np.random.default_rng(1)
-    for (ny, nx) in ((20, 31), (33, 33), (48, 64), (64, 40), (5, 6), (7, 64), (64, 5)):
+    for (ny, nx) in ((20, 31), (33, 33), (48, 64), (64, 40), (5, 6), (7, 64), (64, 5), (65, 64),
+                     (100, 90), (128, 70), (9, 128)):
         for name in ('CC', 'NCC', 'ZNCC', 'zncc', 'other'):
             for up in (1, 3, 10):
                 s = min(ny, nx)
@@ -129,7 +143,7 @@ def test_pair_mode_edge_cases(spx):
 
 def test_shape_and_upsample_limits(spx):
     from subpixal_amd._ffi import SubpixalHipError
-    a = np.zeros((2, 65, 64), np.float32)
+    a = np.zeros((2, 129, 64), np.float32)
     with pytest.raises(SubpixalHipError):
         spx.xcorr_refine_batch(a, a)
     b = np.zeros((2, 64, 64), np.float32)
@@ -148,10 +162,8 @@ def test_find_displacement_goldens(spx, golden_dir):
     g = _load(golden_dir, 'find_displacement.npz')
     keys = {}
     for i in range(len(g['dx'])):
-        if max(g['ny'][i], g['nx'][i]) > 64:
-            continue
         keys.setdefault((int(g['ny'][i]), int(g['nx'][i]), int(g['cc_type'][i])), []).append(i)
-    assert len(keys) >= 20
+    assert len(keys) >= 24
     worst = 0.0
     for (ny, nx, ct), idx in keys.items():
         ref = np.empty((len(idx), ny, nx), np.float32)
@@ -206,7 +218,8 @@ def test_find_displacement_single_call_api(spx, golden_dir):
 
 
 def test_known_answers_from_survey(spx):
-    kats = [(32, 2.0, 0.37, -0.81, 'CC', (0.3715578705207552, -0.8122671381992568)),
+    kats = [(128, 4.0, 2.5, 2.5, 'CC', (2.499999209990804, 2.50000019749875)),
+            (32, 2.0, 0.37, -0.81, 'CC', (0.3715578705207552, -0.8122671381992568)),
             (64, 4.0, 1.234, -2.345, 'CC', (1.2334902807121892, -2.3453374860517293)),
             (64, 4.0, -0.05, 0.0, 'CC', (-0.049773694762176746, -7.4e-08)),
             (64, 4.0, 1.234, -2.345, 'ZNCC', (1.2066915371895917, -2.3232555703747977))]
@@ -272,6 +285,23 @@ def test_generator_matches_host_mirror(spx):
     # different first_index -> a shifted view of the same stream
     ref2, _, _ = synth.gaussian_pairs(4, 64, seed=99, first_index=1005)
     assert np.array_equal(ref2[0].cpu().numpy(), ref[5].cpu().numpy())
+
+
+def test_config3_properties_128(spx):
+    """BASELINE config 3 (128x128, upsample=20) at reduced count: accuracy against the
+    generator's truth for every pair, determinism, batch-permutation equivariance."""
+    import torch
+    from subpixal_amd import synth
+    n_pairs = 20000
+    ref, img, truth = synth.gaussian_pairs(n_pairs, 128, seed=77)
+    d1, st = spx.xcorr_refine_batch(ref, img, upsample=20, return_status=True)
+    assert float((d1 - truth).abs().max()) < 1e-3
+    assert int(st.abs().max()) == 0
+    d2 = spx.xcorr_refine_batch(ref, img, upsample=20)
+    assert torch.equal(d1, d2)
+    perm = torch.randperm(n_pairs, device=ref.device)[:3000]
+    d3 = spx.xcorr_refine_batch(ref[perm].contiguous(), img[perm].contiguous(), upsample=20)
+    assert torch.equal(d3, d1[perm])
 
 
 # ----------------------------------------------------------------------------

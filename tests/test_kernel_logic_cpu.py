@@ -35,6 +35,18 @@ def test_pair_mode_grid_stride_pipeline():
     assert np.array_equal(st, est)
 
 
+def test_pair_mode_128_tile():
+    """cutouts above 64 px: period-256 path (16 classes, workspace, radix-4 combine)"""
+    ref, img, truth = datagen.pair_batch(5, 1, 128)
+    got, st = emu.pair(ref, img, 2)
+    exp, est = orc.xcorr_refine_batch(ref, img, 2)
+    assert np.max(np.abs(got - exp)) < 2e-5 and np.array_equal(st, est)
+    r, i = datagen.pair_set(100, 90, 0.7, -1.1, 5.0, 1.3, np.float32)
+    got, st = emu.pair(r[None], i[None], 1, 2)
+    e = orc.xcorr_refine(r, i, 1, 'ZNCC')
+    assert np.max(np.abs(got[0] - np.array(e))) < 2e-5
+
+
 def test_pair_mode_shapes_and_cc_types():
     rng = np.random.default_rng(1)
     for (ny, nx) in ((20, 31), (64, 40), (5, 6)):
