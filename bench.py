@@ -95,6 +95,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--pairs', type=int, default=PAIRS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--tile', type=int, default=TILE, help='cutout side (64 = config 2, 128 = config 3)')
+    ap.add_argument('--upsample', type=int, default=UPSAMPLE)
+    ap.add_argument('--backend', default='nccl', help="'gloo' + --one-device rehearses the N>1 path on one GPU")
+    ap.add_argument('--one-device', action='store_true', help='every rank uses cuda:0 (rehearsal only)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -115,22 +119,35 @@ def main():
     import subpixal_amd
     from subpixal_amd import synth, dist as spx_dist
 
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    on_cpu = world > 1 and args.backend != 'nccl'      # gloo rehearsal: collectives on host copies
+
+    def gather(d):
+        if world == 1:
+            return d
+        return spx_dist.gather_shifts(d.cpu() if on_cpu else d, n_total=n_total, dst=0)
 
     n_local = args.pairs
     n_total = n_local * world
     # inputs generated on the device, resident in HBM before the timed region
-    ref, img, truth = synth.gaussian_pairs(n_local, TILE, seed=20261003,
+    tile, ups = args.tile, args.upsample
+    bytes_per_pair = 2 * tile * tile * 4 + 16 + 4
+    ref, img, truth = synth.gaussian_pairs(n_local, tile, seed=20261003,
                                            first_index=rank * n_local, dev=local_rank)
     torch.cuda.synchronize()
 
     def step():
-        d = subpixal_amd.xcorr_refine_batch(ref, img, upsample=UPSAMPLE)
-        g = spx_dist.gather_shifts(d, n_total=n_total, dst=0) if world > 1 else d
+        d = subpixal_amd.xcorr_refine_batch(ref, img, upsample=ups)
+        g = gather(d)
         return d, g
 
     def barrier():
@@ -151,15 +168,14 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()                 # torch's current stream == the launch stream
-        d = subpixal_amd.xcorr_refine_batch(ref, img, upsample=UPSAMPLE)
+        d = subpixal_amd.xcorr_refine_batch(ref, img, upsample=ups)
         ev[k][1].record()
-        if world > 1:
-            spx_dist.gather_shifts(d, n_total=n_total, dst=0)
+        gather(d)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if on_cpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
@@ -170,14 +186,14 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')))
-            if pmc.get('pairs_per_launch') == n_local:
+            if pmc.get('pairs_per_launch') == n_local and tile == TILE and ups == UPSAMPLE:
                 traffic = pmc['hbm_bytes_per_launch']
         except (OSError, ValueError, KeyError):
             pass
         value = n_total * args.steps / elapsed
-        achieved = n_local * BYTES_PER_PAIR / (kern_ms * 1e-3) / 1e9
+        achieved = n_local * bytes_per_pair / (kern_ms * 1e-3) / 1e9
         out = {
-            'metric': 'cutout cross-correlations/sec (64x64 px, upsample=10)',
+            'metric': 'cutout cross-correlations/sec (%dx%d px, upsample=%d)' % (tile, tile, ups),
             'value': value,
             'unit': 'cross-correlations/s',
             'n_gpus': world,
@@ -190,9 +206,10 @@ def main():
             'dtype': 'f32',
             'data': 'synthetic',
             'config': {
-                'workload': 'BASELINE.json configs[1]: %d 64x64 Gaussian-spot cutout pairs per GPU, '
-                            'upsample=10, inputs resident in HBM' % n_local,
-                'pairs_per_gpu': n_local, 'tile': TILE, 'upsample': UPSAMPLE, 'cc_type': 'CC',
+                'workload': 'BASELINE.json configs[%d]: %d %dx%d Gaussian-spot cutout pairs per GPU, '
+                            'upsample=%d, inputs resident in HBM' % (1 if tile <= 64 else 2, n_local,
+                                                                     tile, tile, ups),
+                'pairs_per_gpu': n_local, 'tile': tile, 'upsample': ups, 'cc_type': 'CC',
                 'parallelism': 'batch sharded over %d GPU(s); gather of (dx,dy) to rank 0' % world,
             },
             'roofline': {
@@ -203,10 +220,10 @@ def main():
                 'frac': achieved / HBM_PEAK_GBS,
                 'traffic': traffic,
                 'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01/pmc_traffic.json)',
-                'algorithmic_bytes_per_launch': n_local * BYTES_PER_PAIR,
-                'kernel': 'spx::pair_kernel<2,1>',
+                'algorithmic_bytes_per_launch': n_local * bytes_per_pair,
+                'kernel': 'spx::pair_kernel<2,1>' if tile <= 64 else 'spx::pair128_kernel<2>',
                 'kernel_ms': kern_ms,
-                'bytes_per_pair': BYTES_PER_PAIR,
+                'bytes_per_pair': bytes_per_pair,
                 'pairs_per_launch': n_local,
             },
             'max_abs_err_px_vs_truth': err,

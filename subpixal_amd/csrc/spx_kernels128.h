@@ -24,8 +24,12 @@ struct Lds128 {
     static constexpr int ZBUF_BYTES = 2 * 64 * ZS * 4;
     static constexpr int XCH_WAVE_BYTES = 64 * XS * 4;
     static constexpr int XCH_BYTES = 4 * XCH_WAVE_BYTES;
-    static constexpr int FB_OFF = R_OFF + XCH_BYTES;       // 4 per-wave fine windows
-    static constexpr int total(int W) { return FB_OFF + 4 * W * W * 4; }
+    // the 4 per-wave fine windows reuse the exchange region, which is idle during the
+    // arg-max / refine / fit tail: 72.7 KiB in all -> two workgroups per CU
+    static constexpr int FB_OFF = R_OFF;
+    static constexpr int total(int W) {
+        return R_OFF + (XCH_BYTES > 4 * W * W * 4 ? XCH_BYTES : 4 * W * W * 4);
+    }
 };
 constexpr size_t kWs128PlaneFloats = 64 * 64;
 constexpr size_t kWs128Bytes = (size_t)(16 * 2 * 64 * 64 + 256 * 256) * sizeof(float);
