@@ -249,14 +249,33 @@ SPX_DEVICE bool better(float v, int i, float bv, int bi) {
 // `slot` (0/1) selects one of two scratch areas: consecutive calls alternate slots, and a
 // slot is only rewritten after at least one more workgroup barrier, so no trailing
 // barrier is needed.
+template <int STEP> SPX_DEVICE void argmax_step(float& v, int& idx) {
+    const float ov = rt::row_xchg<STEP>(v);
+    const int oi = rt::row_xchg<STEP>(idx);
+    if (better(ov, oi, v, idx)) { v = ov; idx = oi; }
+}
+// wave-wide (value, index) arg-max: 4 DPP steps inside each row of 16 lanes, then the
+// four row results through readlane (scalar)
+SPX_DEVICE void wave_argmax(float& v, int& idx) {
+    argmax_step<0>(v, idx);
+    argmax_step<1>(v, idx);
+    argmax_step<2>(v, idx);
+    argmax_step<3>(v, idx);
+    float bv = rt::read_lane(v, 0);
+    int bi = rt::read_lane(idx, 0);
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        const float ov = rt::read_lane(v, 16 * r);
+        const int oi = rt::read_lane(idx, 16 * r);
+        if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    v = bv;
+    idx = bi;
+}
+
 SPX_DEVICE void block_argmax(unsigned char* lds_scr, float& v, int& idx, int slot) {
     const int tid = rt::thread_id();
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        float ov = rt::shfl_xor(v, m);
-        int oi = rt::shfl_xor(idx, m);
-        if (better(ov, oi, v, idx)) { v = ov; idx = oi; }
-    }
+    wave_argmax(v, idx);
     float* rf = reinterpret_cast<float*>(lds_scr + SCR_RED_F) + 8 * slot;
     int* ri = reinterpret_cast<int*>(lds_scr + SCR_RED_F) + 8 * slot + 4;
     if ((tid & 63) == 0) { rf[tid >> 6] = v; ri[tid >> 6] = idx; }
@@ -427,6 +446,12 @@ SPX_DEVICE float balance_factor(unsigned char* lds_scr, float (&ssq)[2]) {
     return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, ratio) & 0x7f800000u);
 }
 
+// Physical column of plane element (row, col): an XOR swizzle on column bits 3-4 by the
+// row's low two bits.  It makes the plane writes of cc_planes (4 rows x 8 columns per
+// 32-lane group) and the 2-row MFMA operand reads bank-conflict free, keeps groups of 8
+// columns contiguous (16-byte reads stay aligned), and costs two integer ops.
+SPX_DEVICE int plane_col(int row, int col) { return col ^ (((row & 1) << 4) | ((row & 2) << 2)); }
+
 // Diagnostic early exit for phase timing (tools/phase_timing.py, `make diag`): DBG
 // is a template parameter, 0 in the product library, so production code carries none
 // of it.  A stopped variant folds its registers into one float per lane and stores
@@ -563,15 +588,22 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk) {
     // class post-twiddle conj(w_P^{8 (cy y1 + cx x1)}); half the imaginary part is kept.
     // The plane goes into this wave's own exchange buffer (its reads above are done).
     float* plane = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::PLANE_STRIDE_BYTES);
+    if (cy) {
 #pragma unroll
-    for (int y1 = 0; y1 < 8; ++y1) {
-        const cf wy = tw[8 * cy * y1];
+        for (int y1 = 1; y1 < 8; ++y1) {
+            const cf wy = tw[8 * cy * y1];
 #pragma unroll
-        for (int x1 = 0; x1 < 8; ++x1) {
-            const cf wx = tw[8 * cx * x1];
-            const cf w = cmul(wy, wx);
+            for (int x1 = 0; x1 < 8; ++x1) v[y1][x1] = cmulc(v[y1][x1], wy);
+        }
+    }
+#pragma unroll
+    for (int x1 = 0; x1 < 8; ++x1) {
+        const cf wx = cx ? tw[8 * cx * x1] : cf{1.0f, 0.0f};
+#pragma unroll
+        for (int y1 = 0; y1 < 8; ++y1) {
             const cf a = v[y1][x1];
-            plane[(l1 + 8 * y1) * L::PS + l0 + 8 * x1] = 0.5f * (a.y * w.x - a.x * w.y);  // Im(a conj w)/2
+            const int row = l1 + 8 * y1;
+            plane[row * L::PS + plane_col(row, l0 + 8 * x1)] = 0.5f * (a.y * wx.x - a.x * wx.y);  // Im(a conj w)/2
         }
     }
     rt::block_sync_lds();
@@ -596,7 +628,7 @@ SPX_DEVICE float window_value(const unsigned char* lds, int ny, int nx, int qy, 
     float acc = 0.0f;
 #pragma unroll
     for (int c = 0; c < C * C; ++c) {
-        const float d = planes[c * (L::PLANE_STRIDE_BYTES / 4) + my * L::PS + mx];
+        const float d = planes[c * (L::PLANE_STRIDE_BYTES / 4) + my * L::PS + plane_col(my, mx)];
         const int neg = ((c / C) & sy) ^ ((c % C) & sx);
         acc += neg ? -d : d;
     }
@@ -748,7 +780,7 @@ SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB>& ft,
             const float sgn = (cy && ((m >> 6) & 1)) ? -1.0f : 1.0f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float afrag = plane[row * L::PS + col[t]];
+                const float afrag = plane[row * L::PS + plane_col(row, col[t])];
 #pragma unroll
                 for (int ab = 0; ab < WB; ++ab)
                     acc[ab][t] = rt::mfma_16x16x4(afrag, sgn * kb[ab][e], acc[ab][t]);
@@ -850,7 +882,7 @@ SPX_DEVICE void coarse_argmax(const unsigned char* lds, int ny, int nx, float ou
 #pragma unroll
         for (int c = 0; c < C * C; ++c)
             d[c] = *reinterpret_cast<const f32x4*>(lds + L::R_OFF + c * L::PLANE_STRIDE_BYTES +
-                                                   (my * L::PS + mx4) * 4);
+                                                   (my * L::PS + plane_col(my, mx4)) * 4);
         if (qy < 0) continue;                      // row outside the window
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

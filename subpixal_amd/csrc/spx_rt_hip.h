@@ -79,18 +79,18 @@ SPX_DEVICE void atomic_add_u64(unsigned long long* p, unsigned long long v) { at
 // ---------------------------------------------------------------------------
 // a * w
 SPX_DEVICE f32x2 cmul(f32x2 a, f32x2 w) {
-    f32x2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
-        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    f32x2 r;      // one statement: hipcc pads separate asm statements with s_nop
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=&v"(r) : "v"(a), "v"(w));
     return r;
 }
 // a * conj(w)
 SPX_DEVICE f32x2 cmulc(f32x2 a, f32x2 w) {
-    f32x2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
-        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=&v"(r) : "v"(a), "v"(w));
     return r;
 }
 // s + (-i) d = (s.x + d.y, s.y - d.x)
@@ -128,6 +128,22 @@ SPX_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 SPX_DEVICE float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 SPX_DEVICE int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
 SPX_DEVICE double shfl_xor(double v, int m) { return __shfl_xor(v, m, 64); }
+
+// DPP lane exchanges inside a row of 16 lanes (no LDS round trip, unlike ds_bpermute):
+// 0 = lane^1, 1 = lane^2, 2 = mirror within 8 lanes, 3 = mirror within 16 lanes.
+template <int STEP> struct DppCtrl {
+    static constexpr int value = STEP == 0 ? 0xB1 : STEP == 1 ? 0x4E : STEP == 2 ? 0x141 : 0x140;
+};
+template <int STEP> SPX_DEVICE int row_xchg(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, DppCtrl<STEP>::value, 0xF, 0xF, false);
+}
+template <int STEP> SPX_DEVICE float row_xchg(float v) {
+    return __builtin_bit_cast(float, row_xchg<STEP>(__builtin_bit_cast(int, v)));
+}
+SPX_DEVICE float read_lane(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+SPX_DEVICE int read_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
 // v_mfma_f32_16x16x4_f32: lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15];
 // D[row=4*(l>>4)+r][col=l&15] in register r.  Exact f32 fma chain over k.

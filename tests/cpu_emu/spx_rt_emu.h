@@ -100,6 +100,24 @@ SPX_DEVICE int shfl_xor(int v, int m) {
     return r;
 }
 
+template <typename T> SPX_DEVICE T shfl_lane(T v, int src, T* slot) {
+    WaveState& w = my_wave();
+    int lane = ctx().tid & 63;
+    slot[lane] = v;
+    w.bar->arrive_and_wait();
+    T r = slot[src];
+    w.bar->arrive_and_wait();
+    return r;
+}
+inline int row_src(int step, int lane) {
+    return step == 0 ? lane ^ 1 : step == 1 ? lane ^ 2
+         : step == 2 ? ((lane & ~7) | (7 - (lane & 7))) : ((lane & ~15) | (15 - (lane & 15)));
+}
+template <int STEP> SPX_DEVICE float row_xchg(float v) { return shfl_lane(v, row_src(STEP, ctx().tid & 63), my_wave().fa); }
+template <int STEP> SPX_DEVICE int row_xchg(int v) { return shfl_lane(v, row_src(STEP, ctx().tid & 63), my_wave().ia); }
+SPX_DEVICE float read_lane(float v, int lane) { return shfl_lane(v, lane, my_wave().fa); }
+SPX_DEVICE int read_lane(int v, int lane) { return shfl_lane(v, lane, my_wave().ia); }
+
 SPX_DEVICE double shfl_xor(double v, int m) {
     WaveState& w = my_wave();
     int lane = ctx().tid & 63;
