@@ -100,7 +100,14 @@ int ktab256_for(DeviceTables* t, int upsample, const float** out) {
 
 // workgroups of a 128-tile launch (each owns one 768 KiB workspace slot)
 int64_t grid128(int num_cu, int64_t nbatch) {
-    const int64_t cap = (int64_t)num_cu * 2;
+    // SPX_GRID128_PER_CU (tuning knob, default 2): resident workgroups per CU; each owns
+    // 768 KiB of workspace, and the total should stay inside the 256 MiB Infinity Cache
+    static const int per_cu = [] {
+        const char* e = getenv("SPX_GRID128_PER_CU");
+        const int v = e ? atoi(e) : 2;
+        return v >= 1 && v <= 4 ? v : 2;
+    }();
+    const int64_t cap = (int64_t)num_cu * per_cu;
     return nbatch < cap ? nbatch : cap;
 }
 int device_cus() {

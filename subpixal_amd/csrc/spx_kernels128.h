@@ -42,6 +42,34 @@ SPX_DEVICE void stage_block128(unsigned char* lds, const float* __restrict__ ref
     const int tid = fresh_tid();
     float* zre = reinterpret_cast<float*>(lds + L::R_OFF);
     float* zim = zre + 64 * L::ZS;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(img)) & 15) == 0;
+    if (aligned && (nx & 3) == 0 && 64 * sy + 64 <= ny && 64 * sx + 64 <= nx) {
+        // block entirely inside the cutout: 16-byte loads, image rows read back to front
+        const int nx4 = nx >> 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * kThreads;
+            const int yl = idx >> 4, x4 = idx & 15;
+            const int y = yl + 64 * sy, xq = x4 + 16 * sx;
+            const f32x4 r = reinterpret_cast<const f32x4*>(ref)[(int64_t)y * nx4 + xq];
+            const f32x4 t = reinterpret_cast<const f32x4*>(img)[(int64_t)(ny - 1 - y) * nx4 + (nx4 - 1 - xq)];
+            float rr[4] = {r[0], r[1], r[2], r[3]};
+            float mm[4] = {t[3], t[2], t[1], t[0]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ns.active) {
+                    if (mm[e] != 0.0f) { mm[e] = mm[e] - ns.im_mean; mm[e] = mm[e] / ns.im_std; }
+                    rr[e] = rr[e] - ns.ref_mean;
+                    rr[e] = rr[e] / ns.ref_std;
+                }
+                mm[e] *= bal;
+            }
+            *reinterpret_cast<f32x4*>(zre + yl * L::ZS + (x4 << 2)) = f32x4{rr[0], rr[1], rr[2], rr[3]};
+            *reinterpret_cast<f32x4*>(zim + yl * L::ZS + (x4 << 2)) = f32x4{mm[0], mm[1], mm[2], mm[3]};
+        }
+        return;
+    }
+#pragma unroll 4
     for (int idx = tid; idx < 64 * 64; idx += kThreads) {
         const int yl = idx >> 6, xl = idx & 63;
         const int y = yl + 64 * sy, x = xl + 64 * sx;
@@ -66,6 +94,7 @@ SPX_DEVICE float balance128(unsigned char* scr, const float* __restrict__ ref,
                             const float* __restrict__ img, int ny, int nx, const NormStats& ns) {
     const int tid = fresh_tid();
     float ssq[2] = {0.0f, 0.0f};
+#pragma unroll 8
     for (int i = tid; i < ny * nx; i += kThreads) {
         float r = ref[i], m = img[i];
         if (ns.active) {
@@ -205,34 +234,46 @@ SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref
 // conv[l'+64 s] = out_scale * Im( sum_c i^(cy sy + cx sx) g_c[l'] )
 SPX_DEVICE void combine128(const float* __restrict__ ws, float* __restrict__ conv, float out_scale) {
     const int tid = fresh_tid();
-    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
-        cf g[4][4];
+    for (int i4 = tid; i4 < 64 * 64 / 4; i4 += kThreads) {          // 4 consecutive l'x per step
+        f32x4 gre[16], gim[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
-            g[c >> 2][c & 3] = cf{ws[(size_t)(c * 2) * kWs128PlaneFloats + idx],
-                                  ws[(size_t)(c * 2 + 1) * kWs128PlaneFloats + idx]};
-        // DFT-4 with +i along cx, then along cy:  X[s] = sum_c i^(c s) a[c]
-        cf h[4][4];
-#pragma unroll
-        for (int cy = 0; cy < 4; ++cy) {
-            const cf a0 = g[cy][0], a1 = g[cy][1], a2 = g[cy][2], a3 = g[cy][3];
-            const cf e0 = a0 + a2, e1 = a0 - a2, o0 = a1 + a3, o1 = a1 - a3;
-            h[cy][0] = e0 + o0;
-            h[cy][2] = e0 - o0;
-            h[cy][1] = rt::add_pi(e1, o1);      // e1 + i o1
-            h[cy][3] = rt::add_mi(e1, o1);      // e1 - i o1
+        for (int c = 0; c < 16; ++c) {
+            gre[c] = reinterpret_cast<const f32x4*>(ws + (size_t)(c * 2) * kWs128PlaneFloats)[i4];
+            gim[c] = reinterpret_cast<const f32x4*>(ws + (size_t)(c * 2 + 1) * kWs128PlaneFloats)[i4];
         }
-        const int ly = idx >> 6, lx = idx & 63;
+        const int ly = i4 >> 4, lx = (i4 & 15) << 2;
+        f32x4 o[4][4];                                               // [sy][sx]
 #pragma unroll
-        for (int sx = 0; sx < 4; ++sx) {
-            const cf a0 = h[0][sx], a1 = h[1][sx], a2 = h[2][sx], a3 = h[3][sx];
-            const cf e0 = a0 + a2, e1 = a0 - a2, o0 = a1 + a3, o1 = a1 - a3;
-            const cf x0 = e0 + o0, x2 = e0 - o0, x1 = rt::add_pi(e1, o1), x3 = rt::add_mi(e1, o1);
-            conv[(size_t)(ly + 0) * 256 + lx + 64 * sx] = out_scale * x0.y;
-            conv[(size_t)(ly + 64) * 256 + lx + 64 * sx] = out_scale * x1.y;
-            conv[(size_t)(ly + 128) * 256 + lx + 64 * sx] = out_scale * x2.y;
-            conv[(size_t)(ly + 192) * 256 + lx + 64 * sx] = out_scale * x3.y;
+        for (int e = 0; e < 4; ++e) {
+            // DFT-4 with +i along cx, then along cy:  X[s] = sum_c i^(c s) a[c]
+            cf h[4][4];
+#pragma unroll
+            for (int cy = 0; cy < 4; ++cy) {
+                const cf a0 = cf{gre[cy * 4 + 0][e], gim[cy * 4 + 0][e]};
+                const cf a1 = cf{gre[cy * 4 + 1][e], gim[cy * 4 + 1][e]};
+                const cf a2 = cf{gre[cy * 4 + 2][e], gim[cy * 4 + 2][e]};
+                const cf a3 = cf{gre[cy * 4 + 3][e], gim[cy * 4 + 3][e]};
+                const cf e0 = a0 + a2, e1 = a0 - a2, o0 = a1 + a3, o1 = a1 - a3;
+                h[cy][0] = e0 + o0;
+                h[cy][2] = e0 - o0;
+                h[cy][1] = rt::add_pi(e1, o1);      // e1 + i o1
+                h[cy][3] = rt::add_mi(e1, o1);      // e1 - i o1
+            }
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) {
+                const cf a0 = h[0][sx], a1 = h[1][sx], a2 = h[2][sx], a3 = h[3][sx];
+                const cf e0 = a0 + a2, e1 = a0 - a2, o0 = a1 + a3, o1 = a1 - a3;
+                o[0][sx][e] = out_scale * (e0.y + o0.y);
+                o[2][sx][e] = out_scale * (e0.y - o0.y);
+                o[1][sx][e] = out_scale * rt::add_pi(e1, o1).y;
+                o[3][sx][e] = out_scale * rt::add_mi(e1, o1).y;
+            }
         }
+#pragma unroll
+        for (int sy = 0; sy < 4; ++sy)
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx)
+                *reinterpret_cast<f32x4*>(conv + (size_t)(ly + 64 * sy) * 256 + lx + 64 * sx) = o[sy][sx];
     }
 }
 
@@ -255,17 +296,28 @@ SPX_DEVICE float window_value128(const float* __restrict__ conv, int ny, int nx,
     return conv[(size_t)conv_index(ny, qy) * 256 + conv_index(nx, qx)];
 }
 
-// coarse arg-max over the flipped 'same' window (cutouts up to 128x128)
+// coarse arg-max over the flipped 'same' window (cutouts up to 128x128): the window is rows
+// [loy, loy+ny) x columns [lox, lox+nx) of the convolution, walked in storage order with
+// 16-byte loads; q = (n-1) + lo - l (conv_index inverted).
 SPX_DEVICE void coarse_argmax128(const float* __restrict__ conv, int ny, int nx, float& bv, int& bi) {
     const int tid = fresh_tid();
     bv = -__builtin_inff();
     bi = 0x7fffffff;
-    const int qx = tid & 127;
-    if (qx < nx) {
-        for (int qy = tid >> 7; qy < ny; qy += kThreads / 128) {
-            const float val = window_value128(conv, ny, nx, qy, qx);
+    const int loy = (ny - 1) / 2, lox = (nx - 1) / 2;
+    const int c4lo = lox >> 2;                               // first aligned column chunk
+    const int nchunk = ((lox + nx - 1) >> 2) - c4lo + 1;     // chunks per row (<= 33)
+    const int total = ny * nchunk;
+#pragma unroll 4
+    for (int g = tid; g < total; g += kThreads) {
+        const int ry = g / nchunk, ch = g - ry * nchunk;
+        const int ly = loy + ry, lx4 = (c4lo + ch) << 2;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(conv + (size_t)ly * 256 + lx4);
+        const int qy = (ny - 1) + loy - ly;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int qx = (nx - 1) + lox - (lx4 + e);
             const int idx = qy * nx + qx;
-            if (better(val, idx, bv, bi)) { bv = val; bi = idx; }
+            if (qx >= 0 && qx < nx && better(d[e], idx, bv, bi)) { bv = d[e]; bi = idx; }
         }
     }
 }
@@ -299,6 +351,7 @@ SPX_DEVICE void fine_window128(unsigned char* lds, const float* __restrict__ kta
     int col[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) col[t] = (lxc + 16 * (4 * wave + t) + lj - 128) & 255;
+#pragma unroll 4
     for (int s4 = 0; s4 < 16; ++s4) {
         f32x4 kb[WB];
 #pragma unroll
