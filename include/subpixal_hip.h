@@ -18,6 +18,8 @@
  *                                   peak_search_box, mask)        subpixal/centroid.py:18-236.
  *   spx_gather_cutouts_f32      <-  Cutout.__init__ slicing/fill  subpixal/cutout.py:737-755
  *                                   + masked-pixel zeroing        subpixal/align.py:661.
+ *   spx_label_bboxes_i32        <-  per-source bounding boxes from the segmentation image
+ *                                   subpixal/cutout.py:151-160 (one pass for all sources).
  *   spx_gen_gaussian_pairs_f32  --  synthetic workload generator (bench / tests only).
  *
  * Conventions
@@ -135,10 +137,24 @@ int spx_find_peak_f64(const double* image, const uint8_t* mask, const double* gu
  *   boxes : int32 [nbatch][4] = (x0, y0, width, height), window may overhang the frame
  *   tiles : float32 [nbatch][tny][tnx]; pixels outside the window/frame, masked
  *           or non-finite are written as `fill` (cutout.py:737,755; align.py:661 uses 0)
+ *   seg   : int32 [fny][fnx] segmentation image and ids: int32 [nbatch] the label of each
+ *           box's source, or both NULL; with them, pixels of other labels are `fill` as well
+ *           (cutout.py:190: mask |= ~(segmentation == sid)).
  */
 int spx_gather_cutouts_f32(const float* frame, const uint8_t* fmask, int fny, int fnx,
                            const int32_t* boxes, int64_t nbatch, int tny, int tnx, float fill,
-                           float* tiles, void* stream);
+                           float* tiles, const int32_t* seg, const int32_t* ids, void* stream);
+
+/*
+ * Bounding boxes of every segment of a label image in one pass (replaces the per-source
+ * `segmentation_image == sid` + np.where scans of cutout.py:151-160).
+ *   seg    : int32 [fny][fnx], 0 = background, labels 1..max_label (others ignored)
+ *   boxes  : int32 [max_label + 1][4] = (xmin, ymin, xmax, ymax), inclusive;
+ *            labels without pixels get (INT32_MAX, INT32_MAX, -1, -1)
+ *   counts : int32 [max_label + 1] pixels per label
+ */
+int spx_label_bboxes_i32(const int32_t* seg, int fny, int fnx, int32_t max_label,
+                         int32_t* boxes, int32_t* counts, void* stream);
 
 /*
  * Synthetic Gaussian-spot pairs: pair k = first_index + i has

@@ -529,6 +529,33 @@ def xcorr_refine_batch(ref, img, upsample=1, cc_type='CC', full_grid=None):
 
 
 # --------------------------------------------------------------------------
+# "Next" row: extraction boxes of the primary cutouts.  Restated from the
+# reference source cutout.py:138-175 (that module cannot be imported here -- it needs
+# astropy/stwcs at import time -- so this part is pinned by reading, not by execution).
+# --------------------------------------------------------------------------
+def primary_boxes(segmentation_image, ids=None, pad=1):
+    """(kept_ids, boxes[(x0, y0, w, h)]) the way ``create_primary_cutouts`` derives them:
+    one ``segmentation_image == sid`` scan per source (cutout.py:151-160), edge-touching
+    sources skipped (162-167), padded (139, 169-173)."""
+    seg = np.asarray(segmentation_image)
+    ny, nx = seg.shape
+    pad = int(np.ceil(pad)) if pad >= 0 else int(np.floor(pad))
+    present = np.setdiff1d(np.unique(seg), [0])
+    if ids is not None:
+        present = np.intersect1d(np.asarray(ids), present)
+    kept, boxes = [], []
+    for sid in present:
+        yy, xx = np.where(seg == sid)
+        x1, x2, y1, y2 = xx.min(), xx.max(), yy.min(), yy.max()
+        if x1 <= 0 or y1 <= 0 or x2 >= nx - 1 or y2 >= ny - 1:
+            continue
+        kept.append(sid)
+        boxes.append((x1 - pad, y1 - pad, x2 - x1 + 1 + 2 * pad, y2 - y1 + 1 + 2 * pad))
+    return (np.asarray(kept, dtype=np.int32),
+            np.asarray(boxes, dtype=np.int32).reshape(len(boxes), 4))
+
+
+# --------------------------------------------------------------------------
 # Timing leg used by bench.py's cpu_baseline ("port"): the reference's own
 # composition for one pair at U=1 -- fftconvolve 'same' + find_peak -- in the
 # input dtype, exactly the per-pair work SURVEY.md section 6 timed.

@@ -61,10 +61,14 @@ void gen_pairs_kernel(uint64_t seed, int64_t first_index, int64_t nbatch, int n,
 // Outside the box (tile padding): 0, which leaves the linear cross-correlation
 // unchanged.
 // ---------------------------------------------------------------------------
+// seg/ids (optional): the segmentation image and the label of each box's source; pixels of
+// other labels are written as `fill` too (cutout.py:190: mask |= ~(seg == sid), then
+// align.py:661 zeroes the masked pixels).
 SPX_TKERNEL(256)
 void gather_cutouts_kernel(const float* __restrict__ frame, const uint8_t* __restrict__ fmask,
                            int fny, int fnx, const int32_t* __restrict__ boxes, int64_t nbatch,
-                           int tny, int tnx, float fill, float* __restrict__ tiles) {
+                           int tny, int tnx, float fill, float* __restrict__ tiles,
+                           const int32_t* __restrict__ seg, const int32_t* __restrict__ ids) {
     const int64_t total = nbatch * tny * tnx;
     const int64_t step = rt::grid_size() * 256;
     for (int64_t i = rt::block_id() * 256 + rt::thread_id(); i < total; i += step) {
@@ -79,11 +83,63 @@ void gather_cutouts_kernel(const float* __restrict__ frame, const uint8_t* __res
             v = fill;
             if (fx >= 0 && fx < fnx && fy >= 0 && fy < fny) {
                 const float f = frame[(int64_t)fy * fnx + fx];
-                const bool bad = (fmask && fmask[(int64_t)fy * fnx + fx]) || !(f - f == 0.0f);
+                const bool bad = (fmask && fmask[(int64_t)fy * fnx + fx]) || !(f - f == 0.0f) ||
+                                 (seg && seg[(int64_t)fy * fnx + fx] != ids[b]);
                 if (!bad) v = f;
             }
         }
         tiles[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Bounding boxes of all segments of a label image in ONE pass (the reference scans the
+// whole frame once per source: `segmentation_image == sid` + np.where, cutout.py:151-160,
+// O(N_src * N_pix)).  boxes[l] = (xmin, ymin, xmax, ymax), counts[l] = pixels, for labels
+// 1..max_label; empty labels keep (INT_MAX, INT_MAX, -1, -1, 0).  HBM-bound integer work:
+// 4 bytes read per pixel, atomics only for labelled pixels (runs of equal labels inside a
+// thread's 4 pixels are merged first).
+// ---------------------------------------------------------------------------
+SPX_TKERNEL(256)
+void label_bbox_init_kernel(int32_t* __restrict__ boxes, int32_t* __restrict__ counts, int nlabels) {
+    const int64_t step = rt::grid_size() * 256;
+    for (int64_t i = rt::block_id() * 256 + rt::thread_id(); i < nlabels; i += step) {
+        boxes[4 * i] = 0x7fffffff;
+        boxes[4 * i + 1] = 0x7fffffff;
+        boxes[4 * i + 2] = -1;
+        boxes[4 * i + 3] = -1;
+        counts[i] = 0;
+    }
+}
+
+SPX_DEVICE void label_bbox_flush(int32_t* boxes, int32_t* counts, int label, int max_label, int y,
+                                 int x1, int x2) {
+    if (label <= 0 || label > max_label) return;
+    rt::atomic_min_i32(boxes + 4 * (int64_t)label, x1);
+    rt::atomic_min_i32(boxes + 4 * (int64_t)label + 1, y);
+    rt::atomic_max_i32(boxes + 4 * (int64_t)label + 2, x2);
+    rt::atomic_max_i32(boxes + 4 * (int64_t)label + 3, y);
+    rt::atomic_add_i32(counts + label, x2 - x1 + 1);
+}
+
+SPX_TKERNEL(256)
+void label_bbox_kernel(const int32_t* __restrict__ seg, int fny, int fnx, int max_label,
+                       int32_t* __restrict__ boxes, int32_t* __restrict__ counts) {
+    const int chunks = (fnx + 3) / 4;                       // 4-pixel chunks per row
+    const int64_t total = (int64_t)fny * chunks;
+    const int64_t step = rt::grid_size() * 256;
+    for (int64_t i = rt::block_id() * 256 + rt::thread_id(); i < total; i += step) {
+        const int y = (int)(i / chunks);
+        const int x0 = (int)(i - (int64_t)y * chunks) * 4;
+        int run_label = 0, run_x1 = 0, run_x2 = 0;
+        for (int e = 0; e < 4; ++e) {
+            const int x = x0 + e;
+            const int l = x < fnx ? seg[(int64_t)y * fnx + x] : 0;
+            if (l == run_label) { run_x2 = x; continue; }
+            label_bbox_flush(boxes, counts, run_label, max_label, y, run_x1, run_x2);
+            run_label = l; run_x1 = x; run_x2 = x;
+        }
+        label_bbox_flush(boxes, counts, run_label, max_label, y, run_x1, run_x2);
     }
 }
 

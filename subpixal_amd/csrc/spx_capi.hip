@@ -331,9 +331,11 @@ int spx_find_peak_f64(const double* image, const uint8_t* mask, const double* gu
 
 int spx_gather_cutouts_f32(const float* frame, const uint8_t* fmask, int fny, int fnx,
                            const int32_t* boxes, int64_t nbatch, int tny, int tnx, float fill,
-                           float* tiles, void* stream) {
+                           float* tiles, const int32_t* seg, const int32_t* ids, void* stream) {
     if (nbatch < 0 || (nbatch > 0 && (!frame || !boxes || !tiles)))
         return fail(SPX_E_ARG, "null pointer or negative batch");
+    if ((seg == nullptr) != (ids == nullptr))
+        return fail(SPX_E_ARG, "seg and ids must be given together");
     if (fny < 1 || fnx < 1 || tny < 1 || tnx < 1) return fail(SPX_E_SHAPE, "bad shape");
     if (nbatch == 0) return 0;
     const int64_t total = nbatch * tny * tnx;
@@ -341,7 +343,25 @@ int spx_gather_cutouts_f32(const float* frame, const uint8_t* fmask, int fny, in
     const unsigned grid = (unsigned)(blocks < 65535 * 32 ? blocks : 65535 * 32);
     hipLaunchKernelGGL(spx::gather_cutouts_kernel, dim3(grid), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), frame, fmask, fny, fnx, boxes, nbatch,
-                       tny, tnx, fill, tiles);
+                       tny, tnx, fill, tiles, seg, ids);
+    SPX_HIP(hipGetLastError());
+    return 0;
+}
+
+int spx_label_bboxes_i32(const int32_t* seg, int fny, int fnx, int32_t max_label,
+                         int32_t* boxes, int32_t* counts, void* stream) {
+    if (!seg || !boxes || !counts) return fail(SPX_E_ARG, "null pointer");
+    if (fny < 1 || fnx < 1 || max_label < 0) return fail(SPX_E_SHAPE, "bad shape");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nl = max_label + 1;
+    hipLaunchKernelGGL(spx::label_bbox_init_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, s,
+                       boxes, counts, nl);
+    SPX_HIP(hipGetLastError());
+    const int64_t total = (int64_t)fny * ((fnx + 3) / 4);
+    const int64_t blocks = (total + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+    hipLaunchKernelGGL(spx::label_bbox_kernel, dim3(grid), dim3(256), 0, s, seg, fny, fnx,
+                       (int)max_label, boxes, counts);
     SPX_HIP(hipGetLastError());
     return 0;
 }

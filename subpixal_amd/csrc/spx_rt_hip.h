@@ -71,6 +71,9 @@ SPX_DEVICE unsigned long long clock_stamp() {
     return t;
 }
 SPX_DEVICE void atomic_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
+SPX_DEVICE void atomic_min_i32(int* p, int v) { atomicMin(p, v); }
+SPX_DEVICE void atomic_max_i32(int* p, int v) { atomicMax(p, v); }
+SPX_DEVICE void atomic_add_i32(int* p, int v) { atomicAdd(p, v); }
 
 // ---------------------------------------------------------------------------
 // Packed complex arithmetic on (re, im) register pairs: one VOP3P instruction each,

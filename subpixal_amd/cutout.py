@@ -16,7 +16,8 @@ import torch
 
 from . import _ffi, device
 
-__all__ = ['Cutout', 'NoOverlapError', 'PartialOverlapError', 'pack_cutouts']
+__all__ = ['Cutout', 'NoOverlapError', 'PartialOverlapError', 'pack_cutouts',
+           'segment_bounding_boxes', 'primary_cutout_boxes']
 
 
 class NoOverlapError(ValueError):
@@ -245,12 +246,60 @@ class Cutout(object):
         return [x - (self._blc[0] - self.dx), y - (self._blc[1] - self.dy)]
 
 
-def pack_cutouts(frame, boxes, tile, mask=None, fill=0.0):
+def segment_bounding_boxes(segmentation_image, max_label=None):
+    """Bounding box and pixel count of every label of a segmentation image in one GPU pass
+    (the reference scans the whole frame once per source, cutout.py:151-160).
+
+    Returns ``boxes [max_label + 1, 4]`` int32 = (xmin, ymin, xmax, ymax) inclusive and
+    ``counts [max_label + 1]`` as CUDA tensors; row 0 (background) and absent labels hold
+    (INT32_MAX, INT32_MAX, -1, -1) / 0."""
+    seg = device.to_device(segmentation_image, torch.int32)
+    if seg.dim() != 2:
+        raise ValueError("segmentation image must be 2-D.")
+    if max_label is None:
+        max_label = int(seg.max().item()) if seg.numel() else 0
+    boxes = torch.empty((max_label + 1, 4), dtype=torch.int32, device=seg.device)
+    counts = torch.empty((max_label + 1,), dtype=torch.int32, device=seg.device)
+    lib = _ffi.load()
+    with torch.cuda.device(seg.device):
+        _ffi.check(lib.spx_label_bboxes_i32(device.ptr(seg), seg.shape[0], seg.shape[1], int(max_label),
+                                            device.ptr(boxes), device.ptr(counts), device.stream_ptr()))
+    return boxes, counts
+
+
+def primary_cutout_boxes(segmentation_image, ids=None, pad=1):
+    """Extraction boxes of the primary cutouts, with the reference's rules
+    (``create_primary_cutouts``, cutout.py:138-175): only labels present in the image (and in
+    ``ids`` when given), sources whose segment touches the image border are skipped
+    (cutout.py:162-167), the box is the segment's bounding rectangle grown by ``pad``
+    (rounded away from zero, cutout.py:139).
+
+    Returns ``(kept_ids, boxes)``: numpy int32 arrays, boxes rows ``(x0, y0, width, height)``
+    as :func:`pack_cutouts` takes them."""
+    ny, nx = segmentation_image.shape
+    pad = int(np.ceil(pad)) if pad >= 0 else int(np.floor(pad))
+    bb, cnt = segment_bounding_boxes(segmentation_image)
+    bb = bb.cpu().numpy()
+    cnt = cnt.cpu().numpy()
+    present = np.nonzero(cnt[1:] > 0)[0] + 1
+    if ids is not None:
+        present = np.intersect1d(np.asarray(ids), present)
+    b = bb[present]
+    inside = (b[:, 0] > 0) & (b[:, 1] > 0) & (b[:, 2] < nx - 1) & (b[:, 3] < ny - 1)
+    present, b = present[inside], b[inside]
+    boxes = np.stack([b[:, 0] - pad, b[:, 1] - pad, b[:, 2] - b[:, 0] + 1 + 2 * pad,
+                      b[:, 3] - b[:, 1] + 1 + 2 * pad], axis=1).astype(np.int32)
+    return present.astype(np.int32), boxes
+
+
+def pack_cutouts(frame, boxes, tile, mask=None, fill=0.0, segmentation_image=None, ids=None):
     """Gather ``len(boxes)`` windows of ``frame [fny, fnx]`` into ``tiles [N, tny, tnx]``
     float32 on the device.
 
     boxes : int ``[N, 4]`` rows ``(x0, y0, width, height)``; windows may overhang the
         frame.  mask : bad-pixel booleans ``[fny, fnx]`` (True = bad) or None.
+    segmentation_image, ids : optional label image ``[fny, fnx]`` and the label of each box's
+        source ``[N]``; pixels carrying another label are filled as well (cutout.py:190).
     Inside its window a tile holds the frame pixel, or ``fill`` where the window leaves
     the frame, the pixel is masked or it is not finite; the padding outside the window
     is 0 (which leaves the linear cross-correlation unchanged).
@@ -266,10 +315,18 @@ def pack_cutouts(frame, boxes, tile, mask=None, fill=0.0):
     tny, tnx = int(tile[0]), int(tile[1])
     if int((b[:, 2] > tnx).any()) or int((b[:, 3] > tny).any()):
         raise ValueError("a box is larger than the tile.")
+    if (segmentation_image is None) != (ids is None):
+        raise ValueError("segmentation_image and ids must be given together.")
+    sg = None if segmentation_image is None else device.to_device(segmentation_image, torch.int32)
+    si = None if ids is None else device.to_device(np.asarray(ids, dtype=np.int32)
+                                                   if not isinstance(ids, torch.Tensor) else ids, torch.int32)
+    if sg is not None and (tuple(sg.shape) != tuple(f.shape) or si.shape[0] != b.shape[0]):
+        raise ValueError("segmentation image must match the frame and ids the boxes.")
     tiles = torch.empty((b.shape[0], tny, tnx), dtype=torch.float32, device=f.device)
     lib = _ffi.load()
     with torch.cuda.device(f.device):
         _ffi.check(lib.spx_gather_cutouts_f32(device.ptr(f), device.ptr(m), f.shape[0], f.shape[1],
                                               device.ptr(b), b.shape[0], tny, tnx, float(fill),
-                                              device.ptr(tiles), device.stream_ptr()))
+                                              device.ptr(tiles), device.ptr(sg), device.ptr(si),
+                                              device.stream_ptr()))
     return tiles

@@ -59,10 +59,10 @@ extern "C" int emu_find_peak(const double* image, const uint8_t* mask, const dou
 
 extern "C" int emu_gather(const float* frame, const uint8_t* fmask, int fny, int fnx,
                           const int32_t* boxes, int64_t nbatch, int tny, int tnx, float fill,
-                          float* tiles) {
+                          float* tiles, const int32_t* seg, const int32_t* ids) {
     const int64_t blocks = (nbatch * tny * tnx + 255) / 256;
     rt::launch(blocks < 8 ? blocks : 8, 256, [&] {
-        gather_cutouts_kernel(frame, fmask, fny, fnx, boxes, nbatch, tny, tnx, fill, tiles);
+        gather_cutouts_kernel(frame, fmask, fny, fnx, boxes, nbatch, tny, tnx, fill, tiles, seg, ids);
     });
     return 0;
 }
@@ -109,5 +109,12 @@ extern "C" int emu_disp5_128(const float* ref, const float* im4, int64_t nbatch,
     rt::launch(nbatch, kThreads, [&] {
         disp5_128_kernel(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, wsp);
     });
+    return 0;
+}
+
+extern "C" int emu_label_bboxes(const int32_t* seg, int fny, int fnx, int max_label, int32_t* boxes,
+                                int32_t* counts) {
+    rt::launch(1, 256, [&] { label_bbox_init_kernel(boxes, counts, max_label + 1); });
+    rt::launch(3, 256, [&] { label_bbox_kernel(seg, fny, fnx, max_label, boxes, counts); });
     return 0;
 }

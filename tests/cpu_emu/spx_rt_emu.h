@@ -72,6 +72,10 @@ SPX_DEVICE int launder_lane(int v) { return v; }
 SPX_DEVICE int launder_uniform(int v) { return v; }
 SPX_DEVICE unsigned long long clock_stamp() { return 0; }
 SPX_DEVICE void atomic_add_u64(unsigned long long* p, unsigned long long v) { (void)p; (void)v; }
+// one workgroup at a time, threads are real: use atomics
+SPX_DEVICE void atomic_min_i32(int* p, int v) { int o = __atomic_load_n(p, __ATOMIC_RELAXED); while (v < o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} }
+SPX_DEVICE void atomic_max_i32(int* p, int v) { int o = __atomic_load_n(p, __ATOMIC_RELAXED); while (v > o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} }
+SPX_DEVICE void atomic_add_i32(int* p, int v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 SPX_DEVICE f32x2 cmul(f32x2 a, f32x2 w) { return f32x2{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
 SPX_DEVICE f32x2 cmulc(f32x2 a, f32x2 w) { return f32x2{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y}; }
 SPX_DEVICE f32x2 add_mi(f32x2 s, f32x2 d) { return f32x2{s.x + d.y, s.y - d.x}; }

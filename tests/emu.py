@@ -77,7 +77,18 @@ def find_peak(images, guesses=None, fit=(5, 5), search=(0, 0), masks=None):
     return out, st
 
 
-def gather(frame, fmask, boxes, tny, tnx, fill):
+def label_bboxes(seg, max_label):
+    seg = np.ascontiguousarray(seg, np.int32)
+    boxes = np.zeros((max_label + 1, 4), np.int32)
+    counts = np.zeros(max_label + 1, np.int32)
+    i32 = ctypes.POINTER(ctypes.c_int32)
+    rc = lib().emu_label_bboxes(seg.ctypes.data_as(i32), seg.shape[0], seg.shape[1], int(max_label),
+                                boxes.ctypes.data_as(i32), counts.ctypes.data_as(i32))
+    assert rc == 0
+    return boxes, counts
+
+
+def gather(frame, fmask, boxes, tny, tnx, fill, seg=None, ids=None):
     frame = np.ascontiguousarray(frame, np.float32)
     boxes = np.ascontiguousarray(boxes, np.int32)
     if fmask is not None:
@@ -86,7 +97,9 @@ def gather(frame, fmask, boxes, tny, tnx, fill):
     tiles = np.zeros((n, tny, tnx), np.float32)
     rc = lib().emu_gather(_p(frame, _fp), _p(fmask, _bp), frame.shape[0], frame.shape[1],
                           boxes.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.c_int64(n),
-                          tny, tnx, ctypes.c_float(fill), _p(tiles, _fp))
+                          tny, tnx, ctypes.c_float(fill), _p(tiles, _fp),
+                          None if seg is None else np.ascontiguousarray(seg, np.int32).ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                          None if ids is None else np.ascontiguousarray(ids, np.int32).ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
     assert rc == 0
     return tiles
 

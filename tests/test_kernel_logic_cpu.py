@@ -145,3 +145,35 @@ def test_generator_logic():
     for k in range(3):
         r, i = datagen.pair_set(32, 32, tx[k], ty[k], sg[k], am[k], np.float64)
         assert np.max(np.abs(ref[k] - r)) < 1e-5 and np.max(np.abs(img[k] - i)) < 1e-5
+
+
+def _label_image(rng, ny, nx, nsrc):
+    seg = np.zeros((ny, nx), np.int32)
+    for k in range(1, nsrc + 1):
+        cy, cx = rng.integers(0, ny), rng.integers(0, nx)
+        h, w = rng.integers(1, 9), rng.integers(1, 12)
+        seg[max(0, cy - h):cy + h, max(0, cx - w):cx + w] = k        # later labels overwrite
+    return seg
+
+
+def test_label_bboxes_logic():
+    rng = np.random.default_rng(11)
+    seg = _label_image(rng, 61, 83, 40)
+    boxes, counts = emu.label_bboxes(seg, 45)
+    for l in range(1, 46):
+        yy, xx = np.where(seg == l)
+        if len(yy) == 0:
+            assert counts[l] == 0 and tuple(boxes[l]) == (2**31 - 1, 2**31 - 1, -1, -1)
+        else:
+            assert counts[l] == len(yy)
+            assert tuple(boxes[l]) == (xx.min(), yy.min(), xx.max(), yy.max())
+    # segment-aware gather: pixels of other labels are filled
+    frame = rng.standard_normal(seg.shape).astype(np.float32)
+    ids, bx = orc.primary_boxes(seg, pad=1)
+    assert len(ids) > 5
+    tiles = emu.gather(frame, None, bx, 24, 26, 0.0, seg, ids)
+    for b, (x0, y0, w, h) in enumerate(bx):
+        exp = np.zeros((24, 26), np.float32)
+        sub = seg[y0:y0 + h, x0:x0 + w] == ids[b]
+        exp[:h, :w] = np.where(sub, frame[y0:y0 + h, x0:x0 + w], 0.0)
+        np.testing.assert_array_equal(tiles[b], exp)
