@@ -645,30 +645,52 @@ SPX_DEVICE NormStats norm_stats(unsigned char* lds_scr, const float* __restrict_
     ns.active = 0;
     ns.im_mean = 0.0f; ns.im_std = 1.0f; ns.ref_mean = 0.0f; ns.ref_std = 1.0f;
     if (cc_type == CC_PLAIN) return ns;
-    const int tid = rt::thread_id();
+    const int tid = fresh_tid();
     const int npx = ny * nx;
+    // 16-byte loads when the layout allows it (images are im_stride apart, each npx floats)
+    bool vec = (npx & 3) == 0 && (im_stride & 3) == 0 &&
+               ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(ims)) & 15) == 0;
+    const int nchunk = vec ? npx >> 2 : npx;        // loop units: float4 or float
     // pass 1: counts and sums (pooled image pixels != 0; ref over the union mask)
     double a[4] = {0.0, 0.0, 0.0, 0.0};   // n_im, sum_im, n_union, sum_ref
-    for (int i = tid; i < npx; i += kThreads) {
-        bool any = false;
+#pragma unroll 2
+    for (int i = tid; i < nchunk; i += kThreads) {
+        f32x4 r4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned anym = 0;
+        if (vec) r4 = reinterpret_cast<const f32x4*>(ref)[i]; else r4[0] = ref[i];
         for (int q = 0; q < npool; ++q) {
-            const float m = ims[q * im_stride + i];
-            if (m != 0.0f) { a[0] += 1.0; a[1] += (double)m; any = true; }
+            f32x4 m4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (vec) m4 = reinterpret_cast<const f32x4*>(ims + q * im_stride)[i];
+            else m4[0] = ims[q * im_stride + i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (m4[e] != 0.0f) { a[0] += 1.0; a[1] += (double)m4[e]; anym |= 1u << e; }
         }
-        if (any) { a[2] += 1.0; a[3] += (double)ref[i]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (anym & (1u << e)) { a[2] += 1.0; a[3] += (double)r4[e]; }
     }
     block_sum<4>(lds_scr, a);
     const double im_mean = a[1] / a[0], ref_mean = a[3] / a[2];
     const double n_im = a[0], n_un = a[2];
     // pass 2: population variances about the true means (numpy std, ddof = 0)
     double b[2] = {0.0, 0.0};
-    for (int i = tid; i < npx; i += kThreads) {
-        bool any = false;
+#pragma unroll 2
+    for (int i = tid; i < nchunk; i += kThreads) {
+        f32x4 r4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned anym = 0;
+        if (vec) r4 = reinterpret_cast<const f32x4*>(ref)[i]; else r4[0] = ref[i];
         for (int q = 0; q < npool; ++q) {
-            const float m = ims[q * im_stride + i];
-            if (m != 0.0f) { const double d = (double)m - im_mean; b[0] += d * d; any = true; }
+            f32x4 m4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (vec) m4 = reinterpret_cast<const f32x4*>(ims + q * im_stride)[i];
+            else m4[0] = ims[q * im_stride + i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (m4[e] != 0.0f) { const double d = (double)m4[e] - im_mean; b[0] += d * d; anym |= 1u << e; }
         }
-        if (any) { const double d = (double)ref[i] - ref_mean; b[1] += d * d; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (anym & (1u << e)) { const double d = (double)r4[e] - ref_mean; b[1] += d * d; }
     }
     block_sum<2>(lds_scr, b);
     ns.active = 1;
