@@ -339,3 +339,31 @@ def test_full_size_properties(spx):
     k = 24
     exp, _ = orc.xcorr_refine_batch(ref[:k].cpu().numpy(), img[:k].cpu().numpy(), 10)
     assert np.max(np.abs(d1[:k].cpu().numpy() - exp)) < 2e-4
+
+
+def test_randomized_shapes_sweep(spx):
+    """Seeded sweep over cutout shapes (both tiles), upsampling factors and cc types."""
+    rng = np.random.default_rng(20261003)
+    worst = 0.0
+    for trial in range(48):
+        ny = int(rng.integers(5, 129))
+        nx = int(rng.integers(5, 129))
+        up = int(rng.choice([1, 2, 3, 5, 10, 16]))
+        name = str(rng.choice(['CC', 'NCC', 'ZNCC']))
+        small = min(ny, nx)
+        count = 3
+        ref = np.empty((count, ny, nx), np.float32)
+        img = np.empty_like(ref)
+        for k in range(count):
+            smax = min(2.5, small / 6.0)
+            r, i = datagen.pair_set(ny, nx, rng.uniform(-smax, smax), rng.uniform(-smax, smax),
+                                    max(0.9, small / rng.uniform(8, 14)), rng.uniform(0.5, 2.0), np.float32,
+                                    noise_seed=int(rng.integers(1, 1 << 30)), noise_level=0.003)
+            ref[k], img[k] = r, i
+        got, st = spx.xcorr_refine_batch(ref, img, upsample=up, cc_type=name, return_status=True)
+        exp, est = orc.xcorr_refine_batch(ref, img, up, name)
+        err = float(np.max(np.abs(got - exp)))
+        worst = max(worst, err)
+        assert np.array_equal(st, est), (ny, nx, up, name, st, est)
+        assert err < 1e-3, (ny, nx, up, name, err)
+    print('worst |d| over the sweep: %.3g px' % worst)
