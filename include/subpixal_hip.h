@@ -92,8 +92,8 @@ size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int nee
 
 /*
  * Pair mode.  ref, img: float32 [nbatch][ny][nx].  For every pair: linear
- * cross-correlation on the zero-padded grid (period 128 for cutouts up to 64 px per
- * side, 256 above), arg-max over the flipped
+ * cross-correlation on the zero-padded grid (FFT period 64 / 128 / 256 for cutouts up to
+ * 32 / 64 / 128 px per side: scipy's next_fast_len(2n-1)), arg-max over the flipped
  * 'same' window, U-times trigonometric upsampling around it, 5x5 quadratic fit
  * (find_peak(., 5, 'all')), shift = peak/U - (n-1)//2.
  *   out_dxdy   : float64 [nbatch][2]  (dx, dy)

@@ -3,6 +3,7 @@
 #include "spx_rt_hip.h"
 #include "spx_kernels.h"
 #include "spx_kernels128.h"
+#include "spx_kernels32.h"
 #include "spx_aux_kernels.h"
 #include "spx_tables.h"
 #include "../../include/subpixal_hip.h"
@@ -32,8 +33,10 @@ int hip_fail(hipError_t e, const char* what) {
 struct DeviceTables {
     spx::cf* tw128 = nullptr;                 // w_128^j
     spx::cf* tw256 = nullptr;                 // w_256^j (128 tile)
+    spx::cf* tw64 = nullptr;                  // w_64^j (32 tile)
     std::map<int, float*> ktab;               // upsample -> lane-major tables, 64 tile
     std::map<int, float*> ktab256;            // upsample -> lane-major tables, 128 tile
+    std::map<int, float*> ktab32;             // upsample -> lane-major tables, 32 tile
     int num_cu = 256;
     bool lds_attr_set = false;
 };
@@ -56,6 +59,10 @@ int current_tables(DeviceTables** out) {
         SPX_HIP(hipMalloc(&p, tw2.size() * sizeof(float)));
         SPX_HIP(hipMemcpy(p, tw2.data(), tw2.size() * sizeof(float), hipMemcpyHostToDevice));
         t.tw256 = reinterpret_cast<spx::cf*>(p);
+        std::vector<float> tw3 = spx::host::make_twiddles(64);
+        SPX_HIP(hipMalloc(&p, tw3.size() * sizeof(float)));
+        SPX_HIP(hipMemcpy(p, tw3.data(), tw3.size() * sizeof(float), hipMemcpyHostToDevice));
+        t.tw64 = reinterpret_cast<spx::cf*>(p);
         hipDeviceProp_t prop;
         SPX_HIP(hipGetDeviceProperties(&prop, dev));
         t.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -93,6 +100,23 @@ int ktab256_for(DeviceTables* t, int upsample, const float** out) {
         SPX_HIP(hipMalloc(&p, k.size() * sizeof(float)));
         SPX_HIP(hipMemcpy(p, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
         it = t->ktab256.emplace(upsample, reinterpret_cast<float*>(p)).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+int ktab32_for(DeviceTables* t, int upsample, const float** out) {
+    *out = nullptr;
+    const int wb = spx::host::window_blocks(upsample);
+    if (wb <= 0) return 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = t->ktab32.find(upsample);
+    if (it == t->ktab32.end()) {
+        std::vector<float> k = spx::host::make_ktab32(upsample, 16 * wb);
+        void* p = nullptr;
+        SPX_HIP(hipMalloc(&p, k.size() * sizeof(float)));
+        SPX_HIP(hipMemcpy(p, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
+        it = t->ktab32.emplace(upsample, reinterpret_cast<float*>(p)).first;
     }
     *out = it->second;
     return 0;
@@ -141,6 +165,21 @@ int launch_pair(const DeviceTables* t, const float* ref, const float* img, int64
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(grid_for(t, nbatch)), dim3(spx::kThreads), lds, s, ref, img,
                        nbatch, ny, nx, U, cc_type, t->tw128, ktab, out, status);
+    SPX_HIP(hipGetLastError());
+    return 0;
+}
+
+// 32 tile: one wave per pair, four pairs per workgroup
+template <int WB>
+int launch_pair32(const DeviceTables* t, const float* ref, const float* img, int64_t nbatch, int ny,
+                  int nx, int U, int cc_type, const float* ktab, double* out, int32_t* status,
+                  hipStream_t s) {
+    const int lds = spx::Lds32::total(16 * (WB > 0 ? WB : 1));
+    auto kern = spx::pair32_kernel<WB>;
+    int rc = allow_lds(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid_for(t, (nbatch + 3) / 4)), dim3(spx::kThreads), lds, s, ref,
+                       img, nbatch, ny, nx, U, cc_type, t->tw64, ktab, out, status);
     SPX_HIP(hipGetLastError());
     return 0;
 }
@@ -233,6 +272,17 @@ int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int
         }
     }
     const float* ktab = nullptr;
+    if (ny <= 32 && nx <= 32) {                     // 32 tile, FFT period 64
+        rc = ktab32_for(t, upsample, &ktab);
+        if (rc) return rc;
+        switch (wb) {
+        case 0: return launch_pair32<0>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
+        case 1: return launch_pair32<1>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
+        case 2: return launch_pair32<2>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
+        case 3: return launch_pair32<3>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
+        default: return launch_pair32<4>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
+        }
+    }
     rc = ktab_for(t, upsample, &ktab);
     if (rc) return rc;
     switch (wb) {
@@ -295,6 +345,16 @@ int spx_find_displacement5_f32(const float* ref, const float* im4, int64_t nbatc
         hipLaunchKernelGGL(kern, dim3((unsigned)grid128(t->num_cu, nbatch)), dim3(spx::kThreads), lds, s,
                            ref, im4, nbatch, ny, nx, cc_type, t->tw256, icc, out_dxdy, out_status,
                            reinterpret_cast<float*>(wsb));
+        SPX_HIP(hipGetLastError());
+        return 0;
+    }
+    if (ny <= 32 && nx <= 32) {
+        const int lds32 = spx::Lds32::total(16);
+        auto k32 = spx::disp5_32_kernel;
+        rc = allow_lds(k32, lds32);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k32, dim3(grid_for(t, (nbatch + 3) / 4)), dim3(spx::kThreads), lds32, s, ref, im4,
+                           nbatch, ny, nx, cc_type, t->tw64, icc, out_dxdy, out_status);
         SPX_HIP(hipGetLastError());
         return 0;
     }

@@ -89,20 +89,43 @@ SPX_DEVICE void stage_block128(unsigned char* lds, const float* __restrict__ ref
     }
 }
 
-// sum ref^2 and sum img^2 over the cutout (after normalisation) -> balance factor
+// sum ref^2 and sum img^2 over the cutout (after normalisation) -> balance factor.
+// Latency-bound (2 workgroups/CU): 16-byte loads, 16 of them in flight per thread.
 SPX_DEVICE float balance128(unsigned char* scr, const float* __restrict__ ref,
                             const float* __restrict__ img, int ny, int nx, const NormStats& ns) {
     const int tid = fresh_tid();
     float ssq[2] = {0.0f, 0.0f};
-#pragma unroll 8
-    for (int i = tid; i < ny * nx; i += kThreads) {
-        float r = ref[i], m = img[i];
+    const int npx = ny * nx;
+    const bool vec = (npx & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(img)) & 15) == 0;
+    auto add = [&](float r, float m) {
         if (ns.active) {
             if (m != 0.0f) m = (m - ns.im_mean) / ns.im_std;
             r = (r - ns.ref_mean) / ns.ref_std;
         }
         ssq[0] += r * r;
         ssq[1] += m * m;
+    };
+    if (vec) {
+        const int n4 = npx >> 2;
+        for (int base = 0; base < n4; base += 8 * kThreads) {
+            f32x4 r[8], m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * kThreads + tid;
+                r[u] = i < n4 ? reinterpret_cast<const f32x4*>(ref)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                m[u] = i < n4 ? reinterpret_cast<const f32x4*>(img)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (base + u * kThreads + tid < n4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) add(r[u][e], m[u][e]);
+                }
+        }
+    } else {
+#pragma unroll 8
+        for (int i = tid; i < npx; i += kThreads) add(ref[i], img[i]);
     }
     return balance_factor(scr, ssq);
 }
@@ -307,7 +330,7 @@ SPX_DEVICE void coarse_argmax128(const float* __restrict__ conv, int ny, int nx,
     const int c4lo = lox >> 2;                               // first aligned column chunk
     const int nchunk = ((lox + nx - 1) >> 2) - c4lo + 1;     // chunks per row (<= 33)
     const int total = ny * nchunk;
-#pragma unroll 4
+#pragma unroll 8
     for (int g = tid; g < total; g += kThreads) {
         const int ry = g / nchunk, ch = g - ry * nchunk;
         const int ly = loy + ry, lx4 = (c4lo + ch) << 2;

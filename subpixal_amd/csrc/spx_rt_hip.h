@@ -128,6 +128,13 @@ SPX_DEVICE void consume(float v) { asm volatile("" ::"v"(v)); }
 // keep independent butterflies from being interleaved into a register-pressure spike)
 SPX_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
+// same, but also orders the wave's GLOBAL stores before its later loads (vmcnt drain)
+SPX_DEVICE void wave_sync_mem() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 SPX_DEVICE float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 SPX_DEVICE int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
 SPX_DEVICE double shfl_xor(double v, int m) { return __shfl_xor(v, m, 64); }

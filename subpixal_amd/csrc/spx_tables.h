@@ -68,6 +68,27 @@ inline std::vector<float> make_ktab(int P, int U, int W) {
     return k;
 }
 
+// 32 tile (period 64, 32-lag class planes), spx_kernels32.h fine_window32:
+//   [0][c][blk][lane][s]       = K_c( -(16 blk + lj - W/2)/U - (4 s + lk - 16) ),        s in [0,8)
+//   [1][c][blk][lane][4 t + r] = K_c( -(16 blk + lj - W/2)/U - (16 t + 4 lk + r - 16) ), t in [0,2)
+inline std::vector<float> make_ktab32(int U, int W) {
+    const int blocks = W / 16;
+    std::vector<float> k((size_t)2 * 2 * blocks * 64 * 8);
+    for (int which = 0; which < 2; ++which)
+        for (int c = 0; c < 2; ++c)
+            for (int blk = 0; blk < blocks; ++blk)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 8; ++i) {
+                        const int lk = lane >> 4, lj = lane & 15;
+                        const int m = which == 0 ? (4 * i + lk - 16)
+                                                 : (16 * (i >> 2) + 4 * lk + (i & 3) - 16);
+                        const double t = -(double)(16 * blk + lj - W / 2) / (double)U - (double)m;
+                        k[((((size_t)which * 2 + c) * blocks + blk) * 64 + lane) * 8 + i] =
+                            (float)class_kernel(c, 64, t);
+                    }
+    return k;
+}
+
 // Period-256 real interpolation kernel (128 tile) and its lane-major MFMA tables
 // (spx_kernels128.h fine_window128):
 //   [0][blk][lane][s]       = K(-(16 blk + lj - W/2)/U - (4 s + lk - 128)),        s in [0,64)

@@ -4,6 +4,7 @@
 #include "spx_kernels.h"
 #include "spx_aux_kernels.h"
 #include "spx_kernels128.h"
+#include "spx_kernels32.h"
 #include "spx_tables.h"
 
 using namespace spx;
@@ -116,5 +117,39 @@ extern "C" int emu_label_bboxes(const int32_t* seg, int fny, int fnx, int max_la
                                 int32_t* counts) {
     rt::launch(1, 256, [&] { label_bbox_init_kernel(boxes, counts, max_label + 1); });
     rt::launch(3, 256, [&] { label_bbox_kernel(seg, fny, fnx, max_label, boxes, counts); });
+    return 0;
+}
+
+extern "C" int emu_pair32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
+                          int U, int cc_type, double* out, int* status) {
+    if (ny < 5 || nx < 5 || ny > 32 || nx > 32) return -1;
+    const int wb = host::window_blocks(U);
+    if (wb < 0) return -2;
+    std::vector<float> tw = host::make_twiddles(64);
+    std::vector<float> kt;
+    if (wb > 0) kt = host::make_ktab32(U, 16 * wb);
+    const cf* twp = reinterpret_cast<const cf*>(tw.data());
+    const float* ktp = kt.empty() ? nullptr : kt.data();
+    int64_t grid = (nbatch + 3) / 4;
+    if (g_grid > 0 && g_grid < grid) grid = g_grid;
+    auto run = [&](auto fn) { rt::launch(grid, kThreads, fn); };
+    switch (wb) {
+    case 0: run([&] { pair32_kernel<0>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 1: run([&] { pair32_kernel<1>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 2: run([&] { pair32_kernel<2>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 3: run([&] { pair32_kernel<3>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    default: run([&] { pair32_kernel<4>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    }
+    return 0;
+}
+
+extern "C" int emu_disp5_32(const float* ref, const float* im4, int64_t nbatch, int ny, int nx,
+                            int cc_type, float* icc, double* out, int* status) {
+    if (ny < 3 || nx < 3 || ny > 32 || nx > 32) return -1;
+    std::vector<float> tw = host::make_twiddles(64);
+    const cf* twp = reinterpret_cast<const cf*>(tw.data());
+    rt::launch((nbatch + 3) / 4, kThreads, [&] {
+        disp5_32_kernel(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status);
+    });
     return 0;
 }

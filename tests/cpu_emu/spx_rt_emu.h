@@ -66,6 +66,7 @@ SPX_DEVICE void block_sync_lds() { emu().block_bar->arrive_and_wait(); }
 
 inline WaveState& my_wave() { return emu().waves[ctx().tid >> 6]; }
 SPX_DEVICE void wave_sync() { my_wave().bar->arrive_and_wait(); }
+SPX_DEVICE void wave_sync_mem() { my_wave().bar->arrive_and_wait(); }
 
 template <typename T> SPX_DEVICE T* launder(T* p) { return p; }
 SPX_DEVICE int launder_lane(int v) { return v; }

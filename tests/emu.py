@@ -20,7 +20,7 @@ def lib():
     if _lib is None:
         srcs = [os.path.join(ROOT, 'tests', 'cpu_emu', f) for f in ('emu_kernels.cpp', 'spx_rt_emu.h')]
         srcs += [os.path.join(ROOT, 'subpixal_amd', 'csrc', f)
-                 for f in ('spx_kernels.h', 'spx_kernels128.h', 'spx_aux_kernels.h', 'spx_tables.h')]
+                 for f in ('spx_kernels.h', 'spx_kernels128.h', 'spx_kernels32.h', 'spx_aux_kernels.h', 'spx_tables.h')]
         if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
             subprocess.check_call(['make', '-C', os.path.join(ROOT, 'subpixal_amd', 'csrc'), 'emu'])
         _lib = ctypes.CDLL(LIB)
@@ -41,7 +41,8 @@ def pair(ref, img, upsample=1, cc=0):
     n = ref.shape[0]
     out = np.zeros((n, 2))
     st = np.zeros(n, np.int32)
-    fn = lib().emu_pair128 if max(ref.shape[1:]) > 64 else lib().emu_pair
+    side = max(ref.shape[1:])
+    fn = lib().emu_pair128 if side > 64 else (lib().emu_pair32 if side <= 32 else lib().emu_pair)
     rc = fn(_p(ref, _fp), _p(img, _fp), ctypes.c_int64(n), ref.shape[1], ref.shape[2],
             int(upsample), int(cc), _p(out, _dp), _p(st, _ip))
     assert rc == 0, rc
@@ -55,7 +56,7 @@ def disp5(ref, im4, cc=1):
     out = np.zeros((n, 2))
     st = np.zeros(n, np.int32)
     icc = np.zeros((n, 2 * ny, 2 * nx), np.float32)
-    fn = lib().emu_disp5_128 if max(ny, nx) > 64 else lib().emu_disp5
+    fn = lib().emu_disp5_128 if max(ny, nx) > 64 else (lib().emu_disp5_32 if max(ny, nx) <= 32 else lib().emu_disp5)
     rc = fn(_p(ref, _fp), _p(im4, _fp), ctypes.c_int64(n), ny, nx, int(cc),
             _p(icc, _fp), _p(out, _dp), _p(st, _ip))
     assert rc == 0, rc

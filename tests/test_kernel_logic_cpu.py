@@ -47,6 +47,18 @@ def test_pair_mode_128_tile():
     assert np.max(np.abs(got[0] - np.array(e))) < 2e-5
 
 
+def test_pair_mode_32_tile():
+    """cutouts up to 32 px: period-64 path, one wave per pair, 4 pairs per workgroup"""
+    ref, img, truth = datagen.pair_batch(9, 6, 32)
+    emu.set_grid(1)                  # 6 pairs on one workgroup: waves loop over pairs
+    try:
+        got, st = emu.pair(ref, img, 10)
+    finally:
+        emu.set_grid(0)
+    exp, est = orc.xcorr_refine_batch(ref, img, 10)
+    assert np.max(np.abs(got - exp)) < 1e-4 and np.array_equal(st, est)
+
+
 def test_pair_mode_shapes_and_cc_types():
     rng = np.random.default_rng(1)
     for (ny, nx) in ((20, 31), (64, 40), (5, 6)):
