@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Reduce the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_pmc.sh) to
+profiles/<round>/pmc_traffic.json, the HBM bytes per launch that bench.py reports as
+roofline.traffic.  MI355X_MICROARCH.md (HBM section): both counters are in KiB; the guide's
+gfx950 correction doubles FETCH_SIZE for wide coalesced reads; WRITE_SIZE is exact.
+
+usage: tools/pmc_traffic.py FETCH.csv WRITE.csv [--kernel pair_kernel] [--pairs 100000] [--build TEXT] > out.json
+"""
+import argparse
+import csv
+import json
+
+
+def mean_counter(path, kernel, counter):
+    vals = []
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if kernel in row['Kernel_Name'] and row['Counter_Name'] == counter:
+                vals.append(float(row['Counter_Value']))
+    if not vals:
+        raise SystemExit(f'no {counter} rows for {kernel} in {path}')
+    return sum(vals) / len(vals), len(vals)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('fetch_csv')
+    ap.add_argument('write_csv')
+    ap.add_argument('--kernel', default='pair_kernel')
+    ap.add_argument('--pairs', type=int, default=100000)
+    ap.add_argument('--bytes-per-pair', type=int, default=2 * 64 * 64 * 4 + 20)
+    ap.add_argument('--build', default='')
+    a = ap.parse_args()
+    fetch_kb, nf = mean_counter(a.fetch_csv, a.kernel, 'FETCH_SIZE')
+    write_kb, nw = mean_counter(a.write_csv, a.kernel, 'WRITE_SIZE')
+    rd = 2.0 * fetch_kb * 1024.0
+    wr = write_kb * 1024.0
+    print(json.dumps({
+        'command': 'rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 bench.py '
+                   '--steps 3 --warmup 1 --no-cpu-baseline (one pass per counter, tools/gpu_pmc.sh)',
+        'kernel': a.kernel,
+        'launches_averaged': [nf, nw],
+        'pairs_per_launch': a.pairs,
+        'build': a.build,
+        'FETCH_SIZE_KB_per_launch': fetch_kb,
+        'WRITE_SIZE_KB_per_launch': write_kb,
+        'read_bytes_per_launch': rd,
+        'write_bytes_per_launch': wr,
+        'hbm_bytes_per_launch': rd + wr,
+        'algorithmic_bytes_per_launch': a.pairs * a.bytes_per_pair,
+        'note': 'MI355X_MICROARCH.md (HBM): FETCH_SIZE counts half the bytes of wide coalesced reads on '
+                'gfx950 (doubled here); WRITE_SIZE exact.  Excess over the algorithmic bytes = scratch '
+                'traffic of the remaining spilled VGPRs + constant tables.',
+    }, indent=1))
+
+
+if __name__ == '__main__':
+    main()
