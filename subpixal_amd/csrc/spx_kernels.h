@@ -299,8 +299,37 @@ struct PeakResult {
     int status;
 };
 
-// d: 25 values, row-major (y outer), of the box whose first pixel is (x1, y1);
+// the fit from the six moment sums of the box whose first pixel is (x1, y1);
 // (imax, jmax): integer arg-max; (nx, ny): image size (centroid.py:217-236).
+SPX_DEVICE PeakResult quad_fit_finish(double s0, double sx, double sy, double sxy, double sxx,
+                                      double syy, int x1, int y1, int imax, int jmax, int nx,
+                                      int ny) {
+    const double c10 = sx * (1.0 / 50.0), c01 = sy * (1.0 / 50.0), c11 = sxy * (1.0 / 100.0);
+    const double c20 = (sxx - 2.0 * s0) * (1.0 / 70.0), c02 = (syy - 2.0 * s0) * (1.0 / 70.0);
+    PeakResult r;
+    const double det = 4.0 * c02 * c20 - c11 * c11;
+    if (det <= 0.0 || ((c20 > 0.0 && c02 >= 0.0) || (c20 >= 0.0 && c02 > 0.0))) {
+        r.x = x1 + 2.5;           // (x1 + x2)/2 with x2 exclusive: centroid.py:225
+        r.y = y1 + 2.5;
+        r.status = ST_NOMAX;
+        return r;
+    }
+    const double inv_det = 1.0 / det;
+    const double xm = (x1 + 2) + (c01 * c11 - 2.0 * c02 * c10) * inv_det;
+    const double ym = (y1 + 2) + (c10 * c11 - 2.0 * c01 * c20) * inv_det;
+    if (xm > 0.0 && xm < nx - 1.0 && ym > 0.0 && ym < ny - 1.0) {
+        r.x = xm;
+        r.y = ym;
+        r.status = ST_OK;
+    } else {
+        r.x = (double)imax;       // centroid.py:230-236 (auto_expand_search False)
+        r.y = (double)jmax;
+        r.status = ST_OUTSIDE;
+    }
+    return r;
+}
+
+// d: 25 values, row-major (y outer), of the box whose first pixel is (x1, y1)
 SPX_DEVICE PeakResult quad_fit_5x5(const double* d, int x1, int y1, int imax, int jmax,
                                    int nx, int ny) {
     double s0 = 0, sx = 0, sy = 0, sxy = 0, sxx = 0, syy = 0;
@@ -316,28 +345,37 @@ SPX_DEVICE PeakResult quad_fit_5x5(const double* d, int x1, int y1, int imax, in
             syy += y * y * v;
         }
     }
-    const double c10 = sx / 50.0, c01 = sy / 50.0, c11 = sxy / 100.0;
-    const double c20 = (sxx - 2.0 * s0) / 70.0, c02 = (syy - 2.0 * s0) / 70.0;
-    PeakResult r;
-    const double det = 4.0 * c02 * c20 - c11 * c11;
-    if (det <= 0.0 || ((c20 > 0.0 && c02 >= 0.0) || (c20 >= 0.0 && c02 > 0.0))) {
-        r.x = x1 + 2.5;           // (x1 + x2)/2 with x2 exclusive: centroid.py:225
-        r.y = y1 + 2.5;
-        r.status = ST_NOMAX;
-        return r;
+    return quad_fit_finish(s0, sx, sy, sxy, sxx, syy, x1, y1, imax, jmax, nx, ny);
+}
+
+// The same fit by one whole wave, without LDS: lanes 0..24 pass their box value `v`
+// (row-major); lane j < 6 forms moment j = sum_y wy(y) sum_x wx(x) v(x, y) with
+// (wx, wy) = (1,1) (x,1) (1,y) (x,y) (x^2,1) (1,y^2); every lane then finishes the
+// arithmetic on the broadcast sums.  All 64 lanes must call it.
+SPX_DEVICE PeakResult quad_fit_wave(float v, int lane, int x1, int y1, int imax, int jmax,
+                                    int nx, int ny) {
+    lane = rt::launder_lane(lane);                // keeps the weights out of long-lived registers
+    const int j = lane < 6 ? lane : 0;
+    const int px = (j == 1 || j == 3) ? 1 : (j == 4 ? 2 : 0);
+    const int py = (j == 2 || j == 3) ? 1 : (j == 5 ? 2 : 0);
+    double xw[5], yw[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const double c = (double)(i - 2);
+        xw[i] = px == 0 ? 1.0 : (px == 1 ? c : c * c);
+        yw[i] = py == 0 ? 1.0 : (py == 1 ? c : c * c);
     }
-    const double xm = (x1 + 2) + (c01 * c11 - 2.0 * c02 * c10) / det;
-    const double ym = (y1 + 2) + (c10 * c11 - 2.0 * c01 * c20) / det;
-    if (xm > 0.0 && xm < nx - 1.0 && ym > 0.0 && ym < ny - 1.0) {
-        r.x = xm;
-        r.y = ym;
-        r.status = ST_OK;
-    } else {
-        r.x = (double)imax;       // centroid.py:230-236 (auto_expand_search False)
-        r.y = (double)jmax;
-        r.status = ST_OUTSIDE;
+    double s = 0.0;
+#pragma unroll
+    for (int y = 0; y < 5; ++y) {
+        double row = 0.0;
+#pragma unroll
+        for (int x = 0; x < 5; ++x) row += xw[x] * (double)rt::read_lane(v, 5 * y + x);
+        s += yw[y] * row;
     }
-    return r;
+    const double s0 = rt::read_lane(s, 0), sx = rt::read_lane(s, 1), sy = rt::read_lane(s, 2);
+    const double sxy = rt::read_lane(s, 3), sxx = rt::read_lane(s, 4), syy = rt::read_lane(s, 5);
+    return quad_fit_finish(s0, sx, sy, sxy, sxx, syy, x1, y1, imax, jmax, nx, ny);
 }
 
 // the w_P^j table lives in LDS for the whole life of the workgroup
@@ -352,7 +390,8 @@ template <int C> SPX_DEVICE void load_twiddles(unsigned char* lds, const cf* __r
 // refine / fit tail: one dword per 128-byte line (256 threads x 128 B = the 32 KiB of a
 // full 64x64 pair).  The value is only kept alive until the next staging, where the
 // real 16-byte loads then hit L2 instead of HBM.  (Holding the whole next pair in
-// registers does not work: the kernel is at its VGPR budget and they would spill.)
+// registers does not work: hipcc spills them to scratch right after the loads, which
+// stalls the tail on HBM latency -- measured 20.3e6 vs 22.0e6 pairs/s.)
 SPX_DEVICE float warm_next_pair(const float* __restrict__ ref, const float* __restrict__ img) {
     const int tid = rt::thread_id();
     const float* p = (tid < 128) ? ref + tid * 32 : img + (tid - 128) * 32;
@@ -625,13 +664,14 @@ SPX_DEVICE float window_value(const unsigned char* lds, int ny, int nx, int qy, 
     const int ly = conv_index(ny, qy), lx = conv_index(nx, qx);
     const int my = ly & 63, mx = lx & 63;
     const int sy = (ly >> 6) & 1, sx = (lx >> 6) & 1;
-    float acc = 0.0f;
+    static_assert(C == 2, "");
+    float d[C * C];
 #pragma unroll
-    for (int c = 0; c < C * C; ++c) {
-        const float d = planes[c * (L::PLANE_STRIDE_BYTES / 4) + my * L::PS + plane_col(my, mx)];
-        const int neg = ((c / C) & sy) ^ ((c % C) & sx);
-        acc += neg ? -d : d;
-    }
+    for (int c = 0; c < C * C; ++c)
+        d[c] = planes[c * (L::PLANE_STRIDE_BYTES / 4) + my * L::PS + plane_col(my, mx)];
+    // same association as coarse_argmax: d00 + fx d01 + fy (d10 + fx d11)
+    const float fx = sx ? -1.0f : 1.0f, fy = sy ? -1.0f : 1.0f;
+    const float acc = __builtin_fmaf(fy, __builtin_fmaf(fx, d[3], d[2]), __builtin_fmaf(fx, d[1], d[0]));
     return acc * out_scale;     // out_scale = 1 / (P^2 bal)
 }
 
@@ -789,6 +829,15 @@ SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB>& ft,
     for (int t = 0; t < 4; ++t) col[t] = (lxc + 16 * t + lj - 32) & 63;
 
     // stage 1: G^T[mx''][a] = sum_my'' plane[(lyc+my'')&63][(lxc+mx'')&63] sgn_y K_cy[a][my'']
+    // all 64 A fragments first (the registers of the FFT tile are free here): one LDS
+    // latency instead of one per group of MFMAs
+    float afrag[16][4];
+#pragma unroll
+    for (int step = 0; step < 16; ++step) {
+        const int row = (lyc + 4 * step + lk - 32) & 63;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) afrag[step][t] = plane[row * L::PS + plane_col(row, col[t])];
+    }
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
         f32x4 kb[WB];
@@ -798,14 +847,12 @@ SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB>& ft,
         for (int e = 0; e < 4; ++e) {
             const int step = 4 * s4 + e;
             const int m = lyc + 4 * step + lk - 32;
-            const int row = m & 63;
             const float sgn = (cy && ((m >> 6) & 1)) ? -1.0f : 1.0f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float afrag = plane[row * L::PS + plane_col(row, col[t])];
 #pragma unroll
                 for (int ab = 0; ab < WB; ++ab)
-                    acc[ab][t] = rt::mfma_16x16x4(afrag, sgn * kb[ab][e], acc[ab][t]);
+                    acc[ab][t] = rt::mfma_16x16x4(afrag[step][t], sgn * kb[ab][e], acc[ab][t]);
             }
         }
     }
@@ -886,67 +933,81 @@ SPX_DEVICE float fine_value(const unsigned char* lds, int b, int a) {
 // its flipped window index is q = (n-1) + lo - l (see conv_index).
 // ---------------------------------------------------------------------------
 template <int C>
-SPX_DEVICE void coarse_argmax(const unsigned char* lds, int ny, int nx, float out_scale,
-                              float& bv, int& bi) {
+SPX_DEVICE void coarse_argmax(const unsigned char* lds, int ny, int nx, float& bv, int& bi) {
     typedef Lds<C> L;
+    static_assert(C == 2, "");
     const int tid = fresh_tid();
     const int loy = (ny - 1) / 2, lox = (nx - 1) / 2;
-    bv = -__builtin_inff();
-    bi = 0x7fffffff;
+    const float ninf = -__builtin_inff();
+    // column quantities of this thread's four elements (the same in all four row chunks)
+    const int mx4 = (tid & 15) << 2;
+    int qx[4];
+    float fx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int mx = mx4 + e;
+        const bool wrap = mx < lox;                 // convolution index mx + 64
+        qx[e] = (nx - 1) + lox - mx - (wrap ? 64 : 0);
+        fx[e] = wrap ? -1.0f : 1.0f;                // sign of the odd-x classes there
+    }
+    // values: d00 + fx d01 + fy (d10 + fx d11), unscaled (the scale is a positive power
+    // of two); elements outside the window become -inf
+    float val[4][4];
+    int rowbase[4];
+    float m = ninf;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int g = tid + i * kThreads;          // 1024 float4 chunks per plane
-        const int my = g >> 4, mx4 = (g & 15) << 2;
-        const int ly = my + (my < loy ? 64 : 0);
-        const int qy = (ny - 1) + loy - ly;
-        const int sy = ly >> 6;
+        const int my = (tid >> 4) + 16 * i;         // 1024 float4 chunks per plane
+        const bool wrap = my < loy;
+        const int qy = (ny - 1) + loy - my - (wrap ? 64 : 0);
+        const float fy = wrap ? -1.0f : 1.0f;
+        rowbase[i] = qy * nx;
         f32x4 d[C * C];
 #pragma unroll
         for (int c = 0; c < C * C; ++c)
             d[c] = *reinterpret_cast<const f32x4*>(lds + L::R_OFF + c * L::PLANE_STRIDE_BYTES +
                                                    (my * L::PS + plane_col(my, mx4)) * 4);
-        if (qy < 0) continue;                      // row outside the window
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int mx = mx4 + e;
-            const int lx = mx + (mx < lox ? 64 : 0);
-            const int qx = (nx - 1) + lox - lx;
-            const int sx = lx >> 6;
-            float acc = 0.0f;
-#pragma unroll
-            for (int c = 0; c < C * C; ++c) {
-                const int neg = ((c / C) & sy) ^ ((c % C) & sx);
-                acc += neg ? -d[c][e] : d[c][e];
-            }
-            const float val = acc * out_scale;
-            const int idx = qy * nx + qx;
-            if (qx >= 0 && better(val, idx, bv, bi)) { bv = val; bi = idx; }
+            const float u = __builtin_fmaf(fx[e], d[1][e], d[0][e]);
+            const float t = __builtin_fmaf(fx[e], d[3][e], d[2][e]);
+            const float v = __builtin_fmaf(fy, t, u);
+            val[i][e] = (qy >= 0 && qx[e] >= 0) ? v : ninf;
+            m = __builtin_fmaxf(m, val[i][e]);
         }
     }
+    // smallest window index among this thread's elements equal to its maximum
+    int best = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = (val[i][e] == m) ? rowbase[i] + qx[e] : 0x7fffffff;
+            best = idx < best ? idx : best;
+        }
+    bv = m;
+    bi = best;
 }
 
-// 5x5 fit by wave 0 alone (no workgroup barrier): lanes 0..24 fetch the box values,
-// lanes 0..5 each form one of the six moment sums, lane 0 finishes (quad_fit_5x5's
-// arithmetic, same order of operations per sum).  Other waves return at once; the
-// caller's end-of-pair barrier protects the LDS scratch.
+// 5x5 fit by ONE wave (`fit_wave`, default 0) alone, no workgroup barrier, no LDS: its lanes
+// 0..24 fetch the box values, quad_fit_wave does the rest.  The other waves return at once;
+// the result is valid on every lane of the fitting wave.
 template <typename ValFn>
 SPX_DEVICE PeakResult peak_fit_wave0(unsigned char* lds_scr, int imax, int jmax, int NX, int NY,
-                                     ValFn val) {
-    const int tid = rt::thread_id();
+                                     ValFn val, int fit_wave = 0) {
+    const int tid = rt::thread_id() - 64 * fit_wave;
     PeakResult r;
     r.x = (double)imax; r.y = (double)jmax; r.status = ST_EDGE;
     if (imax == 0 || jmax == 0) return r;              // centroid.py:171-172
-    if (tid >= 64) return r;
+    if (tid < 0 || tid >= 64) return r;
     int x1 = imax - 2, y1 = jmax - 2;                  // centroid.py:165-184
     if (x1 > NX - 5) x1 = NX - 5;
     if (y1 > NY - 5) y1 = NY - 5;
     if (x1 < 0) x1 = 0;
     if (y1 < 0) y1 = 0;
-    double* fit = reinterpret_cast<double*>(lds_scr + SCR_FIT);
-    if (tid < 25) fit[tid] = (double)val(x1 + tid % 5, y1 + tid / 5);
-    rt::wave_sync();
-    if (tid == 0) r = quad_fit_5x5(fit, x1, y1, imax, jmax, NX, NY);
-    return r;
+    const int k = tid < 25 ? tid : 24;
+    const float v = val(x1 + k % 5, y1 + k / 5);
+    return quad_fit_wave(v, tid, x1, y1, imax, jmax, NX, NY);
 }
 
 // ---------------------------------------------------------------------------
@@ -959,7 +1020,7 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
                           const float* __restrict__ ktab, double* __restrict__ out,
                           int* __restrict__ status, unsigned char* lds, PhaseClock<DBG>& clk,
                           const float* __restrict__ next_ref, const float* __restrict__ next_img,
-                          float& warm) {
+                          float& warm, int fit_wave, double inv_u) {
     typedef Lds<C> L;
     ny = rt::launder_uniform(ny);
     nx = rt::launder_uniform(nx);
@@ -985,7 +1046,7 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
     // coarse arg-max over the flipped 'same' window (centroid.py:114-116)
     float bv;
     int bi;
-    coarse_argmax<C>(lds, ny, nx, oscale, bv, bi);
+    coarse_argmax<C>(lds, ny, nx, bv, bi);
     block_argmax(scr, bv, bi, 0);
     int qyc = bi / nx, qxc = bi - (bi / nx) * nx;
     clk.tick(11);
@@ -995,7 +1056,7 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
     if constexpr (WB == 0) {
         pk = peak_fit_wave0(scr, qxc, qyc, nx, ny, [&](int x, int y) {
             return window_value<C>(lds, ny, nx, y, x, oscale);
-        });
+        }, fit_wave);
     } else {
         constexpr int W = 16 * (WB > 0 ? WB : 1);
         const int NX = U * nx, NY = U * ny;
@@ -1005,19 +1066,20 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
             fine_window<C, (WB > 0 ? WB : 1)>(lds, ft, ny, nx, qyc, qxc);
             clk.tick(12);
             if constexpr (DBG == 12) { if (tid == 0) out[0] = (double)fine_value<C, W>(lds, 0, 0); return; }
-            // arg-max over the part of the window inside the virtual image
+            // arg-max over the part of the window inside the virtual image: every wave scans
+            // the whole window itself, so all waves hold the result without another barrier
             const int fx0 = U * qxc - W / 2, fy0 = U * qyc - W / 2;
             float fv = -__builtin_inff();
             int fi = 0x7fffffff;
-            for (int idx = tid; idx < W * W; idx += kThreads) {
+#pragma unroll 4
+            for (int idx = (tid & 63); idx < W * W; idx += 64) {
                 const int a = idx / W, b = idx % W;       // a: y offset, b: x offset
                 const int gy = fy0 + a, gx = fx0 + b;
-                if (gy >= 0 && gy < NY && gx >= 0 && gx < NX) {
-                    const float val = fine_value<C, W>(lds, b, a);
-                    if (better(val, idx, fv, fi)) { fv = val; fi = idx; }
-                }
+                const float val = fine_value<C, W>(lds, b, a);
+                const bool in = gy >= 0 && gy < NY && gx >= 0 && gx < NX;
+                if (in && better(val, idx, fv, fi)) { fv = val; fi = idx; }
             }
-            block_argmax(scr, fv, fi, 1);
+            wave_argmax(fv, fi);
             clk.tick(13);
             if constexpr (DBG == 13) { if (tid == 0) out[0] = (double)fi; return; }
             const int a = fi / W, b = fi % W;
@@ -1037,20 +1099,23 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
             if (!oky) qyc += (a < W / 2) ? -1 : 1;
             qxc = qxc < 0 ? 0 : (qxc > nx - 1 ? nx - 1 : qxc);
             qyc = qyc < 0 ? 0 : (qyc > ny - 1 ? ny - 1 : qyc);
+            rt::block_sync_lds();      // every wave is done with this window before it is rebuilt
         }
+        clk.tick(16);
         if (inside) {
             const int fx0 = U * qxc - W / 2, fy0 = U * qyc - W / 2;
             pk = peak_fit_wave0(scr, imax, jmax, NX, NY, [&](int x, int y) {
                 return fine_value<C, W>(lds, x - fx0, y - fy0);
-            });
+            }, fit_wave);
         } else {
             pk.x = (double)imax; pk.y = (double)jmax; pk.status = ST_WINDOW;
         }
     }
-    if (tid == 0) {
+    clk.tick(17);
+    if (tid == 64 * fit_wave) {
         // cc.py:89-93 with the interlace factor 2 replaced by U
-        out[0] = pk.x / (double)U - (double)((nx - 1) / 2);
-        out[1] = pk.y / (double)U - (double)((ny - 1) / 2);
+        out[0] = pk.x * inv_u - (double)((nx - 1) / 2);
+        out[1] = pk.y * inv_u - (double)((ny - 1) / 2);
         if (status) status[0] = pk.status;
     }
     clk.tick(14);
@@ -1066,16 +1131,29 @@ SPX_TKERNEL(256) void pair_kernel(const float* __restrict__ ref, const float* __
     PhaseClock<DBG> clk;
     clk.start();
     const int64_t stride = (int64_t)ny * nx;
-    const bool full = ny == 64 && nx == 64;
+    const bool full = ny == 64 && nx == 64 &&
+        ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(img)) & 15) == 0;
     const int64_t step = rt::grid_size();
     float warm = 0.0f;
+    // the wave that does the (serial) 5x5 fit rotates from pair to pair, and starts
+    // differently in neighbouring workgroups, so that no SIMD carries it every time
+    int fit_wave = (int)(rt::block_id() & 3);
+    // 1/U once, kept in scalar registers (exact for the reference's U = 2 and every power
+    // of two; otherwise within one ulp of the division)
+    const double inv_u = rt::read_lane(1.0 / (double)U, 0);
     for (int64_t p = rt::block_id(); p < nbatch; p += step) {
         const bool more = full && (p + step < nbatch);
         pair_body<C, WB, DBG>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, tw_g, ktab,
                               out + 2 * p, status ? status + p : nullptr, lds, clk,
                               more ? ref + (p + step) * stride : nullptr,
-                              more ? img + (p + step) * stride : nullptr, warm);
-        rt::block_sync_lds();
+                              more ? img + (p + step) * stride : nullptr, warm, fit_wave, inv_u);
+        fit_wave = (fit_wave + 1) & 3;
+        // upsample > 1: the last workgroup-wide step of a pair is the class sum of the fine
+        // window; after it every wave only reads that window (own arg-max, wave 0's fit),
+        // which the next pair's staging does not touch, so the waves run on into the next
+        // pair and meet again at its first barrier.  upsample = 1 fits on the planes, which
+        // the staging overwrites.
+        if constexpr (WB == 0) rt::block_sync_lds();
         clk.tick(15);
     }
     // diagnostic build: the per-phase cycle totals go to the tail of the status array

@@ -352,11 +352,9 @@ SPX_DEVICE PeakResult peak_fit_wave(double* fit, int imax, int jmax, int NX, int
     if (y1 > NY - 5) y1 = NY - 5;
     if (x1 < 0) x1 = 0;
     if (y1 < 0) y1 = 0;
-    if (lane < 25) fit[lane] = (double)val(x1 + lane % 5, y1 + lane / 5);
-    rt::wave_sync();
-    if (lane == 0) r = quad_fit_5x5(fit, x1, y1, imax, jmax, NX, NY);
-    rt::wave_sync();
-    return r;
+    const int k = lane < 25 ? lane : 24;
+    const float v = val(x1 + k % 5, y1 + k / 5);
+    return quad_fit_wave(v, lane, x1, y1, imax, jmax, NX, NY);
 }
 
 template <int WB>

@@ -46,9 +46,14 @@ SPX_DEVICE void wave_sync() {
 
 // Makes a (wave-uniform) pointer opaque to the optimiser at this point, so loads
 // through it are not hoisted out of the per-pair loop into long-lived registers.
+// The pointer is a GLOBAL one and keeps that address space through the asm: a generic
+// pointer would turn the loads into flat_load, which also ticks lgkmcnt and so makes every
+// LDS wait behind them sit out an L2 round trip.
 template <typename T> SPX_DEVICE T* launder(T* p) {
-    asm volatile("" : "+s"(p));
-    return p;
+    typedef T __attribute__((address_space(1)))* global_ptr;
+    global_ptr g = (global_ptr)p;
+    asm volatile("" : "+s"(g));
+    return (T*)g;
 }
 
 SPX_DEVICE int launder_uniform(int v) {
@@ -154,6 +159,12 @@ SPX_DEVICE float read_lane(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 SPX_DEVICE int read_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+SPX_DEVICE double read_lane(double v, int lane) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 
 // v_mfma_f32_16x16x4_f32: lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15];
 // D[row=4*(l>>4)+r][col=l&15] in register r.  Exact f32 fma chain over k.

@@ -122,6 +122,7 @@ template <int STEP> SPX_DEVICE float row_xchg(float v) { return shfl_lane(v, row
 template <int STEP> SPX_DEVICE int row_xchg(int v) { return shfl_lane(v, row_src(STEP, ctx().tid & 63), my_wave().ia); }
 SPX_DEVICE float read_lane(float v, int lane) { return shfl_lane(v, lane, my_wave().fa); }
 SPX_DEVICE int read_lane(int v, int lane) { return shfl_lane(v, lane, my_wave().ia); }
+SPX_DEVICE double read_lane(double v, int lane) { return shfl_lane(v, lane, my_wave().da); }
 
 SPX_DEVICE double shfl_xor(double v, int m) {
     WaveState& w = my_wave();

@@ -16,7 +16,7 @@ out = torch.empty((N, 2), dtype=torch.float64, device='cuda')
 st = torch.zeros((N + 40,), dtype=torch.int32, device='cuda')
 names = ['stage+norm+balance', 'tile load (+barrier)', 'fwd A: pretw + ffts', 'fwd A: twiddle', 'transpose 1', 'fwd B ffts',
          'Z^2', 'inv A: ffts + twiddle', 'transpose 2', 'inv B ffts', 'planes write (+2 barriers)', 'coarse argmax',
-         'fine window MFMA (+class sum)', 'fine argmax', 'fit + store', 'end barrier']
+         'fine window MFMA (+class sum)', 'fine argmax', 'store', 'end barrier', 'window decision', '5x5 fit (one wave)']
 def run():
     rc = lib.spx_diag_pair_phase(ref.data_ptr(), img.data_ptr(), N, 64, 64, 100, out.data_ptr(), st.data_ptr(),
                                  torch.cuda.current_stream().cuda_stream)
