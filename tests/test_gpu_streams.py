@@ -1,0 +1,81 @@
+"""The C-ABI calls only enqueue work on the caller's stream (include/subpixal_hip.h,
+"Conventions"): they must be capturable into a HIP graph once the constant tables
+exist (spx_prepare), and independent on independent streams.  GPU only."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs(seed, count=2048, n=64):
+    from subpixal_amd import synth
+    return synth.gaussian_pairs(count, n, seed=seed)
+
+
+def test_graph_capture_and_replay():
+    import torch
+    from subpixal_amd import _ffi, cc, device
+    device.init()
+    _ffi.check(_ffi.load().spx_prepare(10))        # tables built before the capture
+    ref, img, _ = _pairs(11)
+    ref2, img2, truth2 = _pairs(12)
+    eager2 = cc.xcorr_refine_batch(ref2, img2, upsample=10)
+    torch.cuda.synchronize()
+
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out, status = cc.xcorr_refine_batch(ref, img, upsample=10, return_status=True)
+    # replay on new data written into the captured input buffers
+    ref.copy_(ref2)
+    img.copy_(img2)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager2)                # same kernel, same inputs: bitwise
+    assert int(status.abs().max()) == 0
+    assert float((out - truth2).abs().max()) < 2e-4
+    # and once more with the first inputs
+    ref1, img1, truth1 = _pairs(11)
+    ref.copy_(ref1)
+    img.copy_(img1)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert float((out - truth1).abs().max()) < 2e-4
+
+
+def test_graph_capture_reference_mode():
+    import torch
+    import datagen
+    from subpixal_amd import cc, device
+    device.init()
+    ref, im4, _ = datagen.dither_batch(3, 64, 48)
+    r = torch.as_tensor(ref, device='cuda')
+    m = torch.as_tensor(im4, device='cuda')
+    eager = cc.find_displacement_batch(r, m, cc_type='NCC')
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = cc.find_displacement_batch(r, m, cc_type='NCC')
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+
+
+def test_two_streams_are_independent():
+    import torch
+    from subpixal_amd import cc, device
+    device.init()
+    ref_a, img_a, truth_a = _pairs(21, count=20000)
+    ref_b, img_b, truth_b = _pairs(22, count=20000)
+    base_a = cc.xcorr_refine_batch(ref_a, img_a, upsample=10)
+    base_b = cc.xcorr_refine_batch(ref_b, img_b, upsample=2)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(sa):
+        out_a = cc.xcorr_refine_batch(ref_a, img_a, upsample=10)
+    with torch.cuda.stream(sb):
+        out_b = cc.xcorr_refine_batch(ref_b, img_b, upsample=2)
+    sa.synchronize()
+    sb.synchronize()
+    assert torch.equal(out_a, base_a)
+    assert torch.equal(out_b, base_b)
+    assert float((out_a - truth_a).abs().max()) < 2e-4
