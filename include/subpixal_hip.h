@@ -20,6 +20,12 @@
  *                                   + masked-pixel zeroing        subpixal/align.py:661.
  *   spx_label_bboxes_i32        <-  per-source bounding boxes from the segmentation image
  *                                   subpixal/cutout.py:151-160 (one pass for all sources).
+ *   spx_blot_affine4_f32        <-  the four blot_cutout(dzct, imct) calls per source of
+ *                                   subpixal/align.py:664-676 (blot.py:79-155, drizzlepac
+ *                                   tblot, interp='poly5') for coordinate maps that are
+ *                                   affine over a cutout; drizzlepac is not in the reference
+ *                                   tree, the quintic is restated from the published (IRAF
+ *                                   bipoly5 / Everett) formula: parity UNPINNED.
  *   spx_gen_gaussian_pairs_f32  --  synthetic workload generator (bench / tests only).
  *
  * Conventions
@@ -155,6 +161,22 @@ int spx_gather_cutouts_f32(const float* frame, const uint8_t* fmask, int fny, in
  */
 int spx_label_bboxes_i32(const int32_t* seg, int fny, int fnx, int32_t max_label,
                          int32_t* boxes, int32_t* counts, void* stream);
+
+/*
+ * Half-pixel dithered blots: for every source the four images image00, image10, image01,
+ * image11 that spx_find_displacement5_f32 takes (align.py:664-676), resampled from the
+ * source's drizzled cutout with the separable quintic ('poly5') interpolant.
+ *   src    : float32 [nbatch][sny][snx] drizzled cutouts (masked pixels already 0), sny, snx >= 6
+ *   affine : float64 [nbatch][6] = (a0..a5): target pixel (x', y') (0-based, un-dithered grid)
+ *            lies at source pixel (a0 x' + a1 y' + a2, a3 x' + a4 y' + a5)
+ *   gain   : float32 [nbatch] factor applied to the samples (blot.py:134-150: exposure-time /
+ *            pixel-area scaling), or NULL for 1
+ *   im4    : float32 [nbatch][4][ny][nx]; dither (ox, oy) in {0, 1/2}^2 (imct.dx -= ox,
+ *            imct.dy -= oy) samples target position (x + ox, y + oy) (cutout.py:1138: cutout
+ *            pixel x lies at image position x + blc - dx); points mapping outside the source are 0.
+ */
+int spx_blot_affine4_f32(const float* src, int64_t nbatch, int sny, int snx, const double* affine,
+                         const float* gain, int ny, int nx, float* im4, void* stream);
 
 /*
  * Synthetic Gaussian-spot pairs: pair k = first_index + i has

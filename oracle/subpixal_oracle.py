@@ -39,7 +39,7 @@ __all__ = [
     'cross_power_spectrum', 'upsampled_cc', 'upsampled_cc_window',
     'xcorr_refine', 'xcorr_refine_batch', 'find_displacement_batch',
     'QUAD_PINV_5X5', 'STATUS_OK', 'STATUS_EDGE', 'STATUS_NOMAX',
-    'STATUS_OUTSIDE',
+    'STATUS_OUTSIDE', 'primary_boxes', 'blot_affine4',
 ]
 
 # per-item status codes shared with the HIP library (include/subpixal_hip.h)
@@ -567,3 +567,73 @@ def pair_shift_u1(ref, img):
     xm, ym = find_peak(cc, peak_fit_box=5, peak_search_box='all')
     ny, nx = cc.shape
     return xm - (nx - 1) // 2, ym - (ny - 1) // 2
+
+
+# ---------------------------------------------------------------------------
+# Half-pixel dithered blots for affine maps (kernel: blot_affine4_kernel).
+# The reference calls drizzlepac's tblot(interp='poly5') four times per source
+# (align.py:664-676, blot.py:140-146); drizzlepac is absent from the reference tree, so
+# this is the published quintic (the degree-5 polynomial through the six nearest samples
+# per axis, separable -- what IRAF's bipoly5 / Everett's formula evaluates) written
+# INDEPENDENTLY of the kernel as Lagrange weights in float64.  Parity with drizzlepac:
+# UNPINNED.  Edge continuation v(-k) = 2 v(0) - v(k); outside the source -> 0.
+# ---------------------------------------------------------------------------
+def _lagrange6(s):
+    """Weights of the samples at offsets -2..3 for a point at fractional offset s in [0, 1]."""
+    nodes = np.arange(-2.0, 4.0)
+    w = np.ones(6)
+    for i in range(6):
+        for j in range(6):
+            if i != j:
+                w[i] *= (s - nodes[j]) / (nodes[i] - nodes[j])
+    return w
+
+
+def _continued(tile, j, i):
+    ny, nx = tile.shape
+
+    def along_x(row, i):
+        if i < 0:
+            return 2.0 * tile[row, 0] - tile[row, -i]
+        if i > nx - 1:
+            return 2.0 * tile[row, nx - 1] - tile[row, 2 * (nx - 1) - i]
+        return tile[row, i]
+
+    if j < 0:
+        return 2.0 * along_x(0, i) - along_x(-j, i)
+    if j > ny - 1:
+        return 2.0 * along_x(ny - 1, i) - along_x(2 * (ny - 1) - j, i)
+    return along_x(j, i)
+
+
+def blot_affine4(src, affine, ny, nx, gain=None):
+    """``im4 [N, 4, ny, nx]`` float64: dithers 00, 10, 01, 11 <-> (ox, oy) in {0, 1/2}^2;
+    ``imct.dx -= ox`` (align.py:668-676) puts cutout pixel x at image position x + blc - dx0 + ox
+    (cutout.py:1138), i.e. the dither samples target position (x + ox, y + oy);
+    target (x', y') -> source (a0 x' + a1 y' + a2, a3 x' + a4 y' + a5)."""
+    src = np.asarray(src, dtype=np.float64)
+    affine = np.asarray(affine, dtype=np.float64)
+    n, sny, snx = src.shape
+    out = np.zeros((n, 4, ny, nx))
+    for b in range(n):
+        a = affine[b]
+        for q in range(4):
+            ox, oy = 0.5 * (q & 1), 0.5 * ((q >> 1) & 1)
+            for y in range(ny):
+                for x in range(nx):
+                    xt, yt = x + ox, y + oy
+                    xs = a[0] * xt + a[1] * yt + a[2]
+                    ys = a[3] * xt + a[4] * yt + a[5]
+                    if not (0.0 <= xs <= snx - 1 and 0.0 <= ys <= sny - 1):
+                        continue
+                    ix, iy = int(np.floor(xs)), int(np.floor(ys))
+                    wx, wy = _lagrange6(xs - ix), _lagrange6(ys - iy)
+                    if ix >= 2 and ix + 3 < snx and iy >= 2 and iy + 3 < sny:
+                        patch = src[b, iy - 2:iy + 4, ix - 2:ix + 4]
+                    else:
+                        patch = np.array([[_continued(src[b], iy - 2 + jj, ix - 2 + ii) for ii in range(6)]
+                                          for jj in range(6)])
+                    out[b, q, y, x] = wy @ patch @ wx
+        if gain is not None:
+            out[b] *= float(gain[b])
+    return out

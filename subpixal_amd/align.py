@@ -22,7 +22,7 @@ import numpy as np
 
 from . import cc
 
-__all__ = ['find_linear_fit', 'iter_linear_fit', 'measure_shifts']
+__all__ = ['find_linear_fit', 'iter_linear_fit', 'measure_shifts', 'measure_shifts_affine']
 
 
 # ----------------------------------------------------------------------------
@@ -144,8 +144,37 @@ def _image_xy(ct, x, y, wcslin):
     return np.array([x + ct.blc[0] - ct.dx + 1.0, y + ct.blc[1] - ct.dy + 1.0])
 
 
+def measure_shifts_affine(img_tiles, drz_tiles, affine, gain=None, cc_type='NCC'):
+    """The loop body of align.py:656-689 with the four blots made on the GPU
+    (``blot.blot_affine4_batch``): ``img_tiles[k]`` and ``drz_tiles[k]`` are 2-D arrays,
+    ``affine[k]`` maps image-cutout pixels to drizzled-cutout pixels.  The blots never leave
+    the device.  Returns ``(dxdy [N, 2], interlaced images, non-shifted blots)``."""
+    import torch
+    from . import blot as _blot
+    n = len(img_tiles)
+    affine = np.asarray(affine, dtype=np.float64).reshape(n, 6)
+    gain = None if gain is None else np.asarray(gain, dtype=np.float32).reshape(n)
+    dxdy = np.empty((n, 2), dtype=np.float64)
+    iccs, blt00 = [None] * n, [None] * n
+    groups = {}
+    for k in range(n):
+        groups.setdefault((np.shape(img_tiles[k]), np.shape(drz_tiles[k])), []).append(k)
+    for (ishape, _), idx in groups.items():
+        ref = torch.as_tensor(np.stack([np.asarray(img_tiles[k], dtype=np.float32) for k in idx])).cuda()
+        src = torch.as_tensor(np.stack([np.asarray(drz_tiles[k], dtype=np.float32) for k in idx])).cuda()
+        im4 = _blot.blot_affine4_batch(src, affine[idx], ishape, None if gain is None else gain[idx])
+        d, icc = cc.find_displacement_batch(ref, im4, cc_type=cc_type, full_output=True)
+        d, icc, b0 = d.cpu().numpy(), icc.cpu().numpy(), im4[:, 0].cpu().numpy()
+        dxdy[idx] = d
+        for j, k in enumerate(idx):
+            iccs[k] = icc[j]
+            blt00[k] = b0[j]
+    return dxdy, iccs, blt00
+
+
 def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
-                    nclip=3, sigma=3.0, use_weights=True, cc_type='NCC', blot=None):
+                    nclip=3, sigma=3.0, use_weights=True, cc_type='NCC', blot=None,
+                    affine=None, gain=None):
     """Linear fit to the displacements (found by cross-correlation) between ``img_cutouts`` and
     the blots of ``drz_cutouts`` onto them.  Same arguments and return value
     ``(fit, interlaced_cc, nonshifted_blts)`` as the reference (align.py:561-745).
@@ -154,6 +183,10 @@ def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
         ``blot_cutout``; called four times per source with the image cutout's grid displaced by
         (0,0), (-1/2,0), (-1/2,-1/2), (0,-1/2) exactly as align.py:664-679.  When None, each element
         of ``drz_cutouts`` must already be the 4-sequence ``(blt00, blt10, blt01, blt11)``.
+    affine : ``[N, 6]`` image-cutout pixel -> drizzled-cutout pixel maps (``blot.affine_from_map``);
+        when given, ``drz_cutouts`` are the drizzled cutouts themselves and the four blots are
+        resampled on the GPU (``blot.blot_affine4_batch``, quintic interpolation), with the optional
+        per-source ``gain`` of blot.py:134-150.  ``blot`` must be None then.
     """
     if not hasattr(img_cutouts, '__iter__'):
         img_cutouts = [img_cutouts]
@@ -170,8 +203,18 @@ def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
     if wcslin is not None and hasattr(wcslin, 'deepcopy'):
         wcslin = wcslin.deepcopy()
 
+    if affine is not None and blot is not None:
+        raise ValueError("Give either a 'blot' callable or 'affine' maps, not both.")
+
+    def data_of(c):
+        return c.data if hasattr(c, 'data') and not isinstance(c, np.ndarray) else np.asarray(c)
+
     blts = []
     for imct, dz in zip(img_cutouts, drz_cutouts):
+        if affine is not None:
+            if hasattr(dz, 'mask') and not isinstance(dz, np.ndarray):
+                dz.data[dz.mask] = 0                                       # align.py:661
+            continue
         if blot is None:
             if len(dz) != 4:
                 raise ValueError("Without a 'blot' callable each element of drz_cutouts must be "
@@ -190,13 +233,15 @@ def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
         imct.dy = dy0
         blts.append((b00, b10, b01, b11))
 
-    def data_of(c):
-        return c.data if hasattr(c, 'data') and not isinstance(c, np.ndarray) else np.asarray(c)
-
-    img_dxy, interlaced_cc = measure_shifts(
-        [data_of(c) for c in img_cutouts],
-        [[data_of(b) for b in four] for four in blts], cc_type=cc_type, full_output=True)
-    nonshifted_blts = [four[0] for four in blts]
+    if affine is not None:
+        img_dxy, interlaced_cc, nonshifted_blts = measure_shifts_affine(
+            [data_of(c) for c in img_cutouts], [data_of(c) for c in drz_cutouts], affine, gain,
+            cc_type=cc_type)
+    else:
+        img_dxy, interlaced_cc = measure_shifts(
+            [data_of(c) for c in img_cutouts],
+            [[data_of(b) for b in four] for four in blts], cc_type=cc_type, full_output=True)
+        nonshifted_blts = [four[0] for four in blts]
 
     xyim = np.empty((npts, 2))
     xyref = np.empty((npts, 2))
@@ -213,7 +258,7 @@ def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
 
     weights = None
     if use_weights:                                                        # align.py:703-716
-        carriers = drz_cutouts if blot is not None else [four[0] for four in blts]
+        carriers = drz_cutouts if (blot is not None or affine is not None) else [four[0] for four in blts]
         weights = [getattr(c, 'src_weight', None) for c in carriers]
         if all(w is None for w in weights):
             weights = None

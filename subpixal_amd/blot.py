@@ -1,0 +1,93 @@
+"""Half-pixel dithered blots on the MI355X.
+
+The reference builds the four inputs of ``cc.find_displacement`` by calling
+``blot.blot_cutout(dzct, imct)`` four times per source with the image cutout's grid
+displaced by half a pixel (/root/reference/subpixal/align.py:664-676); each call runs
+drizzlepac's C ``tblot`` with ``interp='poly5'`` through a Python WCS callback
+(blot.py:79-155).  drizzlepac and the WCS stack are not part of the reference tree, so
+this module does NOT reproduce ``blot_cutout`` itself.  What it provides is the same
+resampling for coordinate maps that are *affine over one cutout* (a local linearisation
+of target-pixel -> source-pixel, excellent over <= 128 px), for all sources and all four
+dithers in one kernel launch: ``spx_blot_affine4_f32``.  The quintic interpolant is
+restated from its published form (IRAF bipoly5 / Everett's formula), see
+``spx_aux_kernels.h``; parity with drizzlepac is unpinned.
+"""
+import numpy as np
+import torch
+
+from . import _ffi, device
+
+__all__ = ['blot_affine4_batch', 'affine_from_map', 'shift_affine']
+
+
+def shift_affine(count, x0=0.0, y0=0.0, scale=1.0):
+    """``[count, 6]`` affines of a pure offset/scale map: target pixel (x, y) lies at source
+    pixel ``(scale*x + x0, scale*y + y0)``; ``x0, y0`` scalars or ``[count]`` arrays."""
+    a = np.zeros((int(count), 6), dtype=np.float64)
+    a[:, 0] = scale
+    a[:, 4] = scale
+    a[:, 2] = x0
+    a[:, 5] = y0
+    return a
+
+
+def affine_from_map(mapping, shape):
+    """Least-squares affine of a coordinate map over one target cutout.
+
+    mapping : callable ``(x, y) -> (xs, ys)`` on 0-based pixel-centre arrays of the
+        un-dithered target grid (e.g. ``lambda x, y: drz.world2pix(*img.pix2world(x, y))``,
+        the composition BlotWCSMap evaluates at blot.py:71-76, shifted to 0-based).
+    shape : ``(ny, nx)`` of the target cutout.
+    Returns ``(affine[6], max_residual_px)``: the residual over a 5x5 grid of probe points
+    says how well the map is affine over the cutout (distortion shows up here).
+    """
+    ny, nx = int(shape[0]), int(shape[1])
+    gx, gy = np.meshgrid(np.linspace(0.0, nx - 1.0, 5), np.linspace(0.0, ny - 1.0, 5))
+    gx, gy = gx.ravel(), gy.ravel()
+    xs, ys = mapping(gx, gy)
+    design = np.stack([gx, gy, np.ones_like(gx)], axis=1)
+    cx, *_ = np.linalg.lstsq(design, np.asarray(xs, dtype=np.float64), rcond=None)
+    cy, *_ = np.linalg.lstsq(design, np.asarray(ys, dtype=np.float64), rcond=None)
+    res = np.hypot(design @ cx - xs, design @ cy - ys).max()
+    return np.concatenate([cx, cy]), float(res)
+
+
+def blot_affine4_batch(src, affine, shape, gain=None):
+    """The four dithered blots of every source.
+
+    src : ``[N, sny, snx]`` float32 drizzled cutouts (masked pixels already zero,
+        align.py:661), torch CUDA tensor or numpy array; sny, snx >= 6.
+    affine : ``[N, 6]`` float64, target pixel ``(x, y)`` -> source pixel
+        ``(a0 x + a1 y + a2, a3 x + a4 y + a5)`` for the un-dithered target grid.
+    shape : ``(ny, nx)`` of the target (image) cutouts.
+    gain : optional ``[N]`` factor on the samples (blot.py:134-150's exposure-time and
+        pixel-area scaling, which depends on header values the caller holds).
+
+    Returns ``im4 [N, 4, ny, nx]`` float32 (image00, image10, image01, image11 as
+    ``find_displacement_batch`` takes them): dither (ox, oy) in {0, 1/2}^2 (the reference's
+    ``imct.dx -= ox; imct.dy -= oy``) samples the target position ``(x + ox, y + oy)``
+    (cutout.py:1138); points mapping outside the source are 0.
+    Torch tensor if ``src`` was one, numpy otherwise.
+    """
+    like_torch = isinstance(src, torch.Tensor)
+    s = device.to_device(src, torch.float32)
+    if s.dim() != 3:
+        raise ValueError("src must have shape [N, sny, snx].")
+    a = device.to_device(np.asarray(affine, dtype=np.float64) if not isinstance(affine, torch.Tensor)
+                         else affine, torch.float64)
+    if a.dim() != 2 or a.shape[1] != 6 or a.shape[0] != s.shape[0]:
+        raise ValueError("affine must have shape [N, 6].")
+    g = None
+    if gain is not None:
+        g = device.to_device(np.asarray(gain, dtype=np.float32) if not isinstance(gain, torch.Tensor)
+                             else gain, torch.float32)
+        if g.dim() != 1 or g.shape[0] != s.shape[0]:
+            raise ValueError("gain must have shape [N].")
+    ny, nx = int(shape[0]), int(shape[1])
+    im4 = torch.empty((s.shape[0], 4, ny, nx), dtype=torch.float32, device=s.device)
+    lib = _ffi.load()
+    with torch.cuda.device(s.device):
+        _ffi.check(lib.spx_blot_affine4_f32(device.ptr(s), s.shape[0], s.shape[1], s.shape[2],
+                                            device.ptr(a), device.ptr(g), ny, nx, device.ptr(im4),
+                                            device.stream_ptr()))
+    return im4 if like_torch else im4.cpu().numpy()

@@ -2,6 +2,7 @@
 //   find_peak_kernel      centroid.find_peak in full generality (centroid.py:18-236)
 //   gather_cutouts_kernel frame -> fixed tiles (cutout.py:737-755, align.py:661)
 //   gen_pairs_kernel      synthetic Gaussian-spot pairs for bench / tests
+//   blot_affine4_kernel   the four half-pixel dithered blots of align.py:664-676 (poly5)
 // Needs spx_rt_hip.h (or the CPU harness) and spx_kernels.h first.
 #pragma once
 
@@ -89,6 +90,88 @@ void gather_cutouts_kernel(const float* __restrict__ frame, const uint8_t* __res
             }
         }
         tiles[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Half-pixel dithered blots: the four `blot_cutout(dzct, imct)` calls of
+// align.py:664-676 for a batch of sources in one launch, for coordinate maps that are
+// affine over a cutout.  The reference resamples through drizzlepac's C `tblot` with
+// interp='poly5' (blot.py:79, 140-146); drizzlepac is not in the reference tree, so this
+// restates the published algorithm: the quintic of IRAF's bipoly5 interpolant in Everett's
+// central-difference form,
+//   f(x0 + s) = t [f0 + (t^2-1)/6 d2f0 + (t^2-1)(t^2-4)/120 d4f0]
+//             + s [f1 + (s^2-1)/6 d2f1 + (s^2-1)(s^2-4)/120 d4f1],   t = 1 - s,
+// applied along x to six rows and then along y; samples outside the source are continued
+// by v(-k) = 2 v(0) - v(k) (and likewise at the far edge); points that map outside the
+// source give 0 (tblot's misval, blot.py:113).  Parity with drizzlepac is UNPINNED.
+//   dither q = 00, 10, 01, 11 <-> (ox, oy) in {0, 1/2}^2: imct.dx -= 0.5 puts cutout pixel x at
+//   image position x + blc - dx0 + 1/2 (cutout.py:1138), so target pixel (x, y) samples the
+//   source at (xs, ys) = A (x + ox, y + oy) + b,  affine = (a0..a5): xs = a0 x' + a1 y' + a2.
+// ---------------------------------------------------------------------------
+SPX_DEVICE float everett5(const float (&c)[6], float s) {
+    const float t = 1.0f - s, s2 = s * s, t2 = t * t;
+    const float cd20 = (1.0f / 6.0f) * (c[3] - 2.0f * c[2] + c[1]);
+    const float cd21 = (1.0f / 6.0f) * (c[4] - 2.0f * c[3] + c[2]);
+    const float cd40 = (1.0f / 120.0f) * (c[0] - 4.0f * c[1] + 6.0f * c[2] - 4.0f * c[3] + c[4]);
+    const float cd41 = (1.0f / 120.0f) * (c[1] - 4.0f * c[2] + 6.0f * c[3] - 4.0f * c[4] + c[5]);
+    return s * (c[3] + (s2 - 1.0f) * (cd21 + (s2 - 4.0f) * cd41)) +
+           t * (c[2] + (t2 - 1.0f) * (cd20 + (t2 - 4.0f) * cd40));
+}
+// sample (j, i) of an [ny][nx] tile with the edge continuation described above
+SPX_DEVICE float blot_sample(const float* __restrict__ src, int ny, int nx, int j, int i) {
+    // continuation index and weights: v(idx) = a v(edge) + b v(mirror)
+    int ie = i, im = i, je = j, jm = j;
+    float ai = 0.0f, bi = 1.0f, aj = 0.0f, bj = 1.0f;
+    if (i < 0) { ie = 0; im = -i; ai = 2.0f; bi = -1.0f; }
+    else if (i > nx - 1) { ie = nx - 1; im = 2 * (nx - 1) - i; ai = 2.0f; bi = -1.0f; }
+    if (j < 0) { je = 0; jm = -j; aj = 2.0f; bj = -1.0f; }
+    else if (j > ny - 1) { je = ny - 1; jm = 2 * (ny - 1) - j; aj = 2.0f; bj = -1.0f; }
+    const float vee = src[(int64_t)je * nx + ie], vem = src[(int64_t)je * nx + im];
+    const float vme = src[(int64_t)jm * nx + ie], vmm = src[(int64_t)jm * nx + im];
+    const float rowe = ai * vee + bi * vem;     // row je, continued along x
+    const float rowm = ai * vme + bi * vmm;     // row jm, continued along x
+    return aj * rowe + bj * rowm;
+}
+
+SPX_TKERNEL(256)
+void blot_affine4_kernel(const float* __restrict__ src, int64_t nbatch, int sny, int snx,
+                         const double* __restrict__ affine, const float* __restrict__ gain,
+                         int ny, int nx, float* __restrict__ im4) {
+    const int64_t per = (int64_t)4 * ny * nx;
+    const int64_t total = nbatch * per;
+    const int64_t step = rt::grid_size() * 256;
+    for (int64_t g = rt::block_id() * 256 + rt::thread_id(); g < total; g += step) {
+        const int64_t b = g / per;
+        const int r = (int)(g - b * per);
+        const int q = r / (ny * nx);                 // 0: 00, 1: 10, 2: 01, 3: 11
+        const int y = (r - q * ny * nx) / nx, x = r % nx;
+        const double ox = (q & 1) ? 0.5 : 0.0, oy = (q & 2) ? 0.5 : 0.0;
+        const double* a = affine + 6 * b;
+        const double xt = (double)x + ox, yt = (double)y + oy;
+        const double xs = a[0] * xt + a[1] * yt + a[2];
+        const double ys = a[3] * xt + a[4] * yt + a[5];
+        float v = 0.0f;
+        if (xs >= 0.0 && xs <= (double)(snx - 1) && ys >= 0.0 && ys <= (double)(sny - 1)) {
+            const int ix = (int)xs, iy = (int)ys;    // floor: both are >= 0
+            const float sx = (float)(xs - (double)ix), sy = (float)(ys - (double)iy);
+            const float* tile = src + b * (int64_t)sny * snx;
+            float col[6];
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) {
+                float c[6];
+                const int j = iy - 2 + jj;
+                const bool inner = j >= 0 && j < sny && ix >= 2 && ix + 3 < snx;
+#pragma unroll
+                for (int ii = 0; ii < 6; ++ii)
+                    c[ii] = inner ? tile[(int64_t)j * snx + ix - 2 + ii]
+                                  : blot_sample(tile, sny, snx, j, ix - 2 + ii);
+                col[jj] = everett5(c, sx);
+            }
+            v = everett5(col, sy);
+            if (gain) v *= gain[b];
+        }
+        im4[g] = v;
     }
 }
 

@@ -602,13 +602,13 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk) {
     fft8_y<-1>(v);
     fft8_x<-1>(v);
 #pragma unroll
-    for (int y0 = 0; y0 < 8; ++y0) {
+    for (int y0 = 1; y0 < 8; ++y0) {          // y0 = 0: w^0
         const cf wy = tw[y0 * (cy + C * l1)];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[y0][j] = cmulc(v[y0][j], wy);
     }
 #pragma unroll
-    for (int x0 = 0; x0 < 8; ++x0) {
+    for (int x0 = 1; x0 < 8; ++x0) {          // x0 = 0: w^0
         const cf wx = tw[x0 * (cx + C * l0)];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j][x0] = cmulc(v[j][x0], wx);

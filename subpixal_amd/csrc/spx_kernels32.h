@@ -188,7 +188,10 @@ SPX_DEVICE float cc_planes32(const cf* tw, float* wbuf, const float* __restrict_
 #pragma unroll
             for (int x0 = 0; x0 < 4; ++x0) {
                 const cf wx = tw[x0 * ((c & 1) + 2 * l0)];
-                SPX_E32(c, y0, x0) = cmulc(cmulc(SPX_E32(c, y0, x0), wy), wx);
+                cf e = SPX_E32(c, y0, x0);
+                if (y0) e = cmulc(e, wy);         // index 0: w^0
+                if (x0) e = cmulc(e, wx);
+                SPX_E32(c, y0, x0) = e;
             }
         }
     transpose_tile<L::XS>(v, wbuf, lane);

@@ -120,6 +120,13 @@ extern "C" int emu_label_bboxes(const int32_t* seg, int fny, int fnx, int max_la
     return 0;
 }
 
+extern "C" int emu_blot_affine4(const float* src, int64_t nbatch, int sny, int snx,
+                               const double* affine, const float* gain, int ny, int nx, float* im4) {
+    if (sny < 6 || snx < 6) return -2;
+    rt::launch(3, 256, [&] { blot_affine4_kernel(src, nbatch, sny, snx, affine, gain, ny, nx, im4); });
+    return 0;
+}
+
 extern "C" int emu_pair32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
                           int U, int cc_type, double* out, int* status) {
     if (ny < 5 || nx < 5 || ny > 32 || nx > 32) return -1;

@@ -62,3 +62,24 @@ def test_argument_errors():
         find_linear_fit([a, a], [(a, a, a, a)])
     with pytest.raises(ValueError, match="four dithered blots"):
         find_linear_fit([a], [(a, a)])
+
+
+def test_affine_from_map_and_shift_affine():
+    from subpixal_amd import blot
+    a = blot.shift_affine(3, x0=[1.0, 2.0, 3.0], y0=0.5, scale=0.8)
+    assert a.shape == (3, 6)
+    assert np.allclose(a[1], [0.8, 0, 2.0, 0, 0.8, 0.5])
+    true = np.array([0.99, 0.02, 5.0, -0.03, 1.01, 7.0])
+
+    def linear(x, y):
+        return true[0] * x + true[1] * y + true[2], true[3] * x + true[4] * y + true[5]
+
+    fit, res = blot.affine_from_map(linear, (64, 48))
+    assert np.allclose(fit, true, atol=1e-12) and res < 1e-10
+
+    def distorted(x, y):
+        xs, ys = linear(x, y)
+        return xs + 1e-5 * (x - 24) ** 2, ys
+
+    fit2, res2 = blot.affine_from_map(distorted, (64, 48))
+    assert 1e-4 < res2 < 1e-2 and np.allclose(fit2[[0, 1, 3, 4]], true[[0, 1, 3, 4]], atol=1e-3)

@@ -189,3 +189,32 @@ def test_label_bboxes_logic():
         sub = seg[y0:y0 + h, x0:x0 + w] == ids[b]
         exp[:h, :w] = np.where(sub, frame[y0:y0 + h, x0:x0 + w], 0.0)
         np.testing.assert_array_equal(tiles[b], exp)
+
+
+def test_blot_affine4_logic_vs_oracle():
+    """Dithered blots (8f-2): the kernel's Everett-form quintic against the oracle's
+    independent Lagrange form in float64; interior, edge continuation, points outside."""
+    rng = np.random.default_rng(0)
+    n, sny, snx, ny, nx = 3, 24, 20, 12, 14
+    src = rng.normal(size=(n, sny, snx)).astype(np.float32)
+    aff = np.array([[1, 0, 3.3, 0, 1, 4.7],                    # interior only
+                    [0.98, 0.05, -1.0, -0.04, 1.01, 2.2],      # rotation, partly outside
+                    [1.3, 0.0, 0.2, 0.0, 1.6, 0.1]])           # scale, touches the far edges
+    gain = np.array([1.0, 2.5, 0.5], np.float32)
+    got = emu.blot_affine4(src, aff, ny, nx, gain)
+    exp = orc.blot_affine4(src, aff, ny, nx, gain)
+    assert got.shape == (n, 4, ny, nx)
+    assert np.abs(got - exp).max() < 5e-6 * np.abs(exp).max()
+    assert ((exp == 0) == (got == 0)).all()                    # same points fall outside
+    # a degree-5 polynomial is reproduced exactly away from the edges
+    yy, xx = np.mgrid[0:sny, 0:snx].astype(float)
+
+    def poly(x, y):
+        return 0.3 + 0.1 * x - 0.02 * y + 0.01 * x * y + 1e-3 * x ** 3 - 2e-4 * y ** 4 + 1e-5 * x ** 5
+
+    a = np.array([[1, 0, 4.25, 0, 1, 5.5]])
+    g = emu.blot_affine4(poly(xx, yy)[None].astype(np.float32), a, 8, 8)
+    for q, (ox, oy) in enumerate(((0, 0), (0.5, 0), (0, 0.5), (0.5, 0.5))):
+        xt = np.arange(8)[None, :] + ox + 4.25
+        yt = np.arange(8)[:, None] + oy + 5.5
+        assert np.abs(g[0, q] - poly(xt, yt)).max() < 2e-6 * np.abs(poly(xt, yt)).max()
