@@ -184,12 +184,12 @@ int launch_pair32(const DeviceTables* t, const float* ref, const float* img, int
     return 0;
 }
 
-template <int WB>
+template <int WB, int DBG = 0>
 int launch_pair128(const DeviceTables* t, const float* ref, const float* img, int64_t nbatch, int ny,
                    int nx, int U, int cc_type, const float* ktab, double* out, int32_t* status,
                    float* ws, hipStream_t s) {
     const int lds = spx::Lds128::total(16 * WB);
-    auto kern = spx::pair128_kernel<WB>;
+    auto kern = spx::pair128_kernel<WB, DBG>;
     int rc = allow_lds(kern, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid128(t->num_cu, nbatch)), dim3(spx::kThreads), lds, s,
@@ -315,6 +315,21 @@ int spx_diag_pair_phase(const float* ref, const float* img, int64_t nbatch, int 
     }
 #undef SPX_PH
     return fail(SPX_E_ARG, "bad phase");
+}
+
+// same for the 128 tile at upsample 20 (full kernel with per-phase stamps only)
+int spx_diag_pair128_phase(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
+                           double* out_dxdy, int32_t* out_status, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    DeviceTables* t = nullptr;
+    int rc = current_tables(&t);
+    if (rc) return rc;
+    if (workspace_bytes < spx_workspace_bytes_xcorr(nbatch, ny, nx)) return fail(SPX_E_WORKSPACE, "workspace");
+    const float* ktab = nullptr;
+    rc = ktab256_for(t, 20, &ktab);
+    if (rc) return rc;
+    return launch_pair128<2, 100>(t, ref, img, nbatch, ny, nx, 20, 0, ktab, out_dxdy, out_status,
+                                  reinterpret_cast<float*>(workspace), reinterpret_cast<hipStream_t>(stream));
 }
 #endif
 

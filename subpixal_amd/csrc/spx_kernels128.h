@@ -10,7 +10,7 @@
 // the full 256x256 real convolution  conv[l'+64s] = Im( sum_c i^(c.s) g_c[l'] ) / 2P^2  there, and
 // the arg-max, the MFMA refine (period-256 Dirichlet kernel, real) and the fit read from it.
 //
-// Workspace per workgroup: 16 x 2 planes of 64x64 floats (512 KiB) + 256x256 floats (256 KiB).
+// Workspace per workgroup: 16 x 2 planes of 64x64 floats (512 KiB) + 256x260 floats (260 KiB).
 #pragma once
 
 namespace spx {
@@ -32,7 +32,11 @@ struct Lds128 {
     }
 };
 constexpr size_t kWs128PlaneFloats = 64 * 64;
-constexpr size_t kWs128Bytes = (size_t)(16 * 2 * 64 * 64 + 256 * 256) * sizeof(float);
+// rows of the 256x256 convolution carry 4 extra columns that repeat columns 0..3, so that any
+// 4 consecutive (circular) columns are contiguous in memory (fine_window128's 16-byte loads)
+constexpr int kConvStride128 = 256 + 4;
+constexpr size_t kWs128Bytes = (size_t)(16 * 2 * 64 * 64 + 256 * kConvStride128) * sizeof(float);
+struct __attribute__((packed, aligned(4))) F32x4U { float v[4]; };   // 16-byte load, 4-byte aligned
 
 // one 64x64 quadrant block (sy, sx) of z = ref + i*bal*flip(img), normalised, into LDS
 SPX_DEVICE void stage_block128(unsigned char* lds, const float* __restrict__ ref,
@@ -131,9 +135,10 @@ SPX_DEVICE float balance128(unsigned char* scr, const float* __restrict__ ref,
 }
 
 // One round: classes (cy, cx = wave) of the staged pair -> complex planes in the workspace.
+template <int DBG>
 SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref,
                                const float* __restrict__ img, int ny, int nx, const NormStats& ns,
-                               float bal, int cy, float* __restrict__ ws) {
+                               float bal, int cy, float* __restrict__ ws, PhaseClock<DBG>& clk) {
     typedef Lds128 L;
     const int tid = fresh_tid();
     const int wave = tid >> 6, lane = tid & 63;
@@ -171,6 +176,7 @@ SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref
         }
         rt::block_sync_lds();
     }
+    clk.tick(1);
     // class pre-twiddle w_P^{c (8 y1)}
     if (cy) {
 #pragma unroll
@@ -234,6 +240,7 @@ SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref
             v[y1][x1] = cmulc(cmulc(v[y1][x1], wy), wx);
         }
     }
+    clk.tick(2);
     // g_c -> workspace planes [class][re|im][64][64], through the wave's LDS buffer so the
     // global stores are 16-byte, row-contiguous
     float* g = ws + (size_t)((cy * 4 + cx) * 2) * kWs128PlaneFloats;
@@ -251,6 +258,7 @@ SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref
                 reinterpret_cast<const f32x4*>(xch)[i * 64 + lane];
         rt::wave_sync();
     }
+    clk.tick(3);
 }
 
 // radix-4 combination of the 16 class planes into the full real convolution:
@@ -295,28 +303,34 @@ SPX_DEVICE void combine128(const float* __restrict__ ws, float* __restrict__ con
 #pragma unroll
         for (int sy = 0; sy < 4; ++sy)
 #pragma unroll
-            for (int sx = 0; sx < 4; ++sx)
-                *reinterpret_cast<f32x4*>(conv + (size_t)(ly + 64 * sy) * 256 + lx + 64 * sx) = o[sy][sx];
+            for (int sx = 0; sx < 4; ++sx) {
+                float* row = conv + (size_t)(ly + 64 * sy) * kConvStride128;
+                *reinterpret_cast<f32x4*>(row + lx + 64 * sx) = o[sy][sx];
+                if (sx == 0 && lx == 0) *reinterpret_cast<f32x4*>(row + 256) = o[sy][sx];   // wrap copy
+            }
     }
 }
 
 // cutout pair -> full 256x256 convolution in the workspace (ends with a full barrier)
+template <int DBG>
 SPX_DEVICE void conv_full128(unsigned char* lds, const float* __restrict__ ref,
                              const float* __restrict__ img, int ny, int nx, const NormStats& ns,
-                             float* __restrict__ ws) {
+                             float* __restrict__ ws, PhaseClock<DBG>& clk) {
     typedef Lds128 L;
     unsigned char* scr = lds + L::SCR_OFF;
     const float bal = balance128(scr, ref, img, ny, nx, ns);
-    for (int cy = 0; cy < 4; ++cy) class_round128(lds, ref, img, ny, nx, ns, bal, cy, ws);
+    clk.tick(0);
+    for (int cy = 0; cy < 4; ++cy) class_round128<DBG>(lds, ref, img, ny, nx, ns, bal, cy, ws, clk);
     rt::block_sync();                    // class planes (global) visible to every wave
     // conv = Im(IFFT(Z^2)) / 2, IFFT normalisation 1/P^2, balance undone
     const float out_scale = 0.5f / ((float)(L::P) * (float)(L::P) * bal);
     combine128(ws, ws + 32 * kWs128PlaneFloats, out_scale);
     rt::block_sync();
+    clk.tick(4);
 }
 
 SPX_DEVICE float window_value128(const float* __restrict__ conv, int ny, int nx, int qy, int qx) {
-    return conv[(size_t)conv_index(ny, qy) * 256 + conv_index(nx, qx)];
+    return conv[(size_t)conv_index(ny, qy) * kConvStride128 + conv_index(nx, qx)];
 }
 
 // coarse arg-max over the flipped 'same' window (cutouts up to 128x128): the window is rows
@@ -334,7 +348,7 @@ SPX_DEVICE void coarse_argmax128(const float* __restrict__ conv, int ny, int nx,
     for (int g = tid; g < total; g += kThreads) {
         const int ry = g / nchunk, ch = g - ry * nchunk;
         const int ly = loy + ry, lx4 = (c4lo + ch) << 2;
-        const f32x4 d = *reinterpret_cast<const f32x4*>(conv + (size_t)ly * 256 + lx4);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(conv + (size_t)ly * kConvStride128 + lx4);
         const int qy = (ny - 1) + loy - ly;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -347,11 +361,14 @@ SPX_DEVICE void coarse_argmax128(const float* __restrict__ conv, int ny, int nx,
 
 // Fine window around flipped coarse index (qyc, qxc) by MFMA, period-256 real kernel
 //   K(t) = 1/256 [1 + 2 sum_{j=1..127} cos(2 pi j t / 256) + cos(pi t)].
+// Wave w contracts all 256 rows for the 64 window columns mx'' in [64 w - 128, 64 w - 64) and
+// leaves its partial window in its own LDS buffer; the reader adds the four (fine_value128).
+// Inside the wave, A-row lj of column tile t is column 64 w + 4 lj + t, so that a lane's four
+// tiles are 4 consecutive columns = ONE 16-byte load per row (64 per lane instead of 256
+// 4-byte ones); accumulator register r of tile t is then column 64 w + 16 lk + 4 r + t.
 // Tables (spx_tables.h make_ktab256), lane = 16 lk + lj:
 //   [0][blk][lane][s]       = K(-(16 blk + lj - W/2)/U - (4 s + lk - 128)),      s in [0,64)
-//   [1][blk][lane][4 t + r] = K(-(16 blk + lj - W/2)/U - (16 t + 4 lk + r - 128)), t in [0,16)
-// Wave w contracts all 256 rows for its 4 column tiles t = 4w..4w+3 and leaves its partial
-// window in its own LDS buffer; the reader adds the four (fine_value128).
+//   [1][blk][lane][4 T + r] = K(-(16 blk + lj - W/2)/U - (64 w + 16 lk + 4 r + t - 128)), T = 4 w + t
 template <int WB>
 SPX_DEVICE void fine_window128(unsigned char* lds, const float* __restrict__ ktab,
                                const float* __restrict__ conv, int ny, int nx, int qyc, int qxc) {
@@ -371,25 +388,25 @@ SPX_DEVICE void fine_window128(unsigned char* lds, const float* __restrict__ kta
     for (int ab = 0; ab < WB; ++ab)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[ab][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int col[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) col[t] = (lxc + 16 * (4 * wave + t) + lj - 128) & 255;
+    const int col0 = (lxc + 64 * wave + 4 * lj - 128) & 255;     // + t, t = 0..3 (wrap copy in the row)
 #pragma unroll 4
     for (int s4 = 0; s4 < 16; ++s4) {
         f32x4 kb[WB];
 #pragma unroll
         for (int ab = 0; ab < WB; ++ab) kb[ab] = kty[(size_t)ab * 64 * 16 + s4];
+        F32x4U a4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int row = (lyc + 4 * (4 * s4 + e) + lk - 128) & 255;
+            a4[e] = *reinterpret_cast<const F32x4U*>(conv + (size_t)row * kConvStride128 + col0);
+        }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float afrag = conv[(size_t)row * 256 + col[t]];
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int ab = 0; ab < WB; ++ab)
-                    acc[ab][t] = rt::mfma_16x16x4(afrag, kb[ab][e], acc[ab][t]);
-            }
-        }
+                    acc[ab][t] = rt::mfma_16x16x4(a4[e].v[t], kb[ab][e], acc[ab][t]);
     }
     f32x4 f[WB][WB];
 #pragma unroll
@@ -430,11 +447,11 @@ template <int W> SPX_DEVICE float fine_value128(const unsigned char* lds, int b,
 // ---------------------------------------------------------------------------
 // pair mode, 128 tile
 // ---------------------------------------------------------------------------
-template <int WB>
+template <int WB, int DBG>
 SPX_DEVICE void pair128_body(const float* __restrict__ ref, const float* __restrict__ img, int ny,
                              int nx, int U, int cc_type, const float* __restrict__ ktab,
                              double* __restrict__ out, int* __restrict__ status,
-                             unsigned char* lds, float* __restrict__ ws) {
+                             unsigned char* lds, float* __restrict__ ws, PhaseClock<DBG>& clk) {
     typedef Lds128 L;
     ny = rt::launder_uniform(ny);
     nx = rt::launder_uniform(nx);
@@ -442,7 +459,7 @@ SPX_DEVICE void pair128_body(const float* __restrict__ ref, const float* __restr
     const int tid = fresh_tid();
     unsigned char* scr = lds + L::SCR_OFF;
     const NormStats ns = norm_stats(scr, ref, img, 1, 0, ny, nx, cc_type);
-    conv_full128(lds, ref, img, ny, nx, ns, ws);
+    conv_full128<DBG>(lds, ref, img, ny, nx, ns, ws, clk);
     const float* conv = ws + 32 * kWs128PlaneFloats;
 
     float bv;
@@ -450,6 +467,7 @@ SPX_DEVICE void pair128_body(const float* __restrict__ ref, const float* __restr
     coarse_argmax128(conv, ny, nx, bv, bi);
     block_argmax(scr, bv, bi, 0);
     int qyc = bi / nx, qxc = bi - (bi / nx) * nx;
+    clk.tick(5);
     PeakResult pk;
     if constexpr (WB == 0) {
         pk = peak_fit_wave0(scr, qxc, qyc, nx, ny, [&](int x, int y) {
@@ -462,6 +480,7 @@ SPX_DEVICE void pair128_body(const float* __restrict__ ref, const float* __restr
         bool inside = false;
         for (int iter = 0; iter < 4; ++iter) {
             fine_window128<(WB > 0 ? WB : 1)>(lds, ktab, conv, ny, nx, qyc, qxc);
+            clk.tick(6);
             const int fx0 = U * qxc - W / 2, fy0 = U * qyc - W / 2;
             float fv = -__builtin_inff();
             int fi = 0x7fffffff;
@@ -474,6 +493,7 @@ SPX_DEVICE void pair128_body(const float* __restrict__ ref, const float* __restr
                 }
             }
             block_argmax(scr, fv, fi, 1);
+            clk.tick(7);
             const int a = fi / W, b = fi % W;
             jmax = fy0 + a;
             imax = fx0 + b;
@@ -505,6 +525,7 @@ SPX_DEVICE void pair128_body(const float* __restrict__ ref, const float* __restr
         out[1] = pk.y / (double)U - (double)((ny - 1) / 2);
         if (status) status[0] = pk.status;
     }
+    clk.tick(8);
 }
 
 SPX_DEVICE void load_twiddles128(unsigned char* lds, const cf* __restrict__ tw_g) {
@@ -513,7 +534,7 @@ SPX_DEVICE void load_twiddles128(unsigned char* lds, const cf* __restrict__ tw_g
     rt::block_sync_lds();
 }
 
-template <int WB>
+template <int WB, int DBG = 0>
 SPX_TKERNEL(256) void pair128_kernel(const float* __restrict__ ref, const float* __restrict__ img,
                                      int64_t nbatch, int ny, int nx, int U, int cc_type,
                                      const cf* __restrict__ tw_g, const float* __restrict__ ktab,
@@ -523,11 +544,17 @@ SPX_TKERNEL(256) void pair128_kernel(const float* __restrict__ ref, const float*
     load_twiddles128(lds, tw_g);
     float* ws = workspace + (size_t)rt::block_id() * (kWs128Bytes / sizeof(float));
     const int64_t stride = (int64_t)ny * nx;
+    PhaseClock<DBG> clk;
+    clk.start();
     for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
-        pair128_body<WB>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, ktab, out + 2 * p,
-                         status ? status + p : nullptr, lds, ws);
+        pair128_body<WB, DBG>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, ktab, out + 2 * p,
+                              status ? status + p : nullptr, lds, ws, clk);
         rt::block_sync();
+        clk.tick(9);
     }
+    // diagnostic build: the per-phase cycle totals go to the tail of the status array
+    if constexpr (DBG == 100)
+        clk.flush(reinterpret_cast<unsigned long long*>(status + nbatch));
 }
 
 // ---------------------------------------------------------------------------
@@ -554,9 +581,10 @@ SPX_TKERNEL(256) void disp5_128_kernel(const float* __restrict__ ref, const floa
         const NormStats ns = norm_stats(scr, r, m4, 4, stride, ny, nx, cc_type);
         float bv = -__builtin_inff();
         int bi = 0x7fffffff;
+        PhaseClock<0> clk;
         for (int q = 0; q < 4; ++q) {
             const int ox = q & 1, oy = q >> 1;
-            conv_full128(lds, r, m4 + q * stride, ny, nx, ns, ws);
+            conv_full128<0>(lds, r, m4 + q * stride, ny, nx, ns, ws, clk);
             const int qx = tid & 127;
             if (qx < nx) {
                 for (int qy = tid >> 7; qy < ny; qy += kThreads / 128) {

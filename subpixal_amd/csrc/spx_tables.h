@@ -92,7 +92,7 @@ inline std::vector<float> make_ktab32(int U, int W) {
 // Period-256 real interpolation kernel (128 tile) and its lane-major MFMA tables
 // (spx_kernels128.h fine_window128):
 //   [0][blk][lane][s]       = K(-(16 blk + lj - W/2)/U - (4 s + lk - 128)),        s in [0,64)
-//   [1][blk][lane][4 t + r] = K(-(16 blk + lj - W/2)/U - (16 t + 4 lk + r - 128)), t in [0,16)
+//   [1][blk][lane][4 T + r] = K(-(16 blk + lj - W/2)/U - (64 w + 16 lk + 4 r + t - 128)), T = 4 w + t
 inline double kernel256(double t) {
     double s = 1.0 + std::cos(kPi * t);
     for (int k = 1; k < 128; ++k) s += 2.0 * std::cos(2.0 * kPi * k * t / 256.0);
@@ -106,8 +106,9 @@ inline std::vector<float> make_ktab256(int U, int W) {
             for (int lane = 0; lane < 64; ++lane)
                 for (int i = 0; i < 64; ++i) {
                     const int lk = lane >> 4, lj = lane & 15;
+                    // [1]: i = 4 T + r, T = 4 w + t  ->  column 64 w + 16 lk + 4 r + t
                     const int m = which == 0 ? (4 * i + lk - 128)
-                                             : (16 * (i >> 2) + 4 * lk + (i & 3) - 128);
+                                             : (64 * (i >> 4) + 16 * lk + 4 * (i & 3) + ((i >> 2) & 3) - 128);
                     const double t = -(double)(16 * blk + lj - W / 2) / (double)U - (double)m;
                     k[(((size_t)which * blocks + blk) * 64 + lane) * 64 + i] = (float)kernel256(t);
                 }
