@@ -1072,8 +1072,9 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
             float fv = -__builtin_inff();
             int fi = 0x7fffffff;
 #pragma unroll 4
-            for (int idx = (tid & 63); idx < W * W; idx += 64) {
-                const int a = idx / W, b = idx % W;       // a: y offset, b: x offset
+            for (int i = (tid & 63); i < W * W; i += 64) {
+                const int b = i / W, a = i % W;           // storage order (x offset major):
+                const int idx = a * W + b;                // conflict-free reads; idx = (y, x) row-major
                 const int gy = fy0 + a, gx = fx0 + b;
                 const float val = fine_value<C, W>(lds, b, a);
                 const bool in = gy >= 0 && gy < NY && gx >= 0 && gx < NX;
