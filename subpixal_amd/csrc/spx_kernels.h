@@ -25,12 +25,13 @@
 // so the cross-correlation is Im(IFFT(Z^2))/2 and the spectral product is a plain
 // element-wise complex SQUARE -- no Z[k] / Z[-k] unpacking, no data exchange.  The
 // inverse runs the same rounds backwards and leaves, per class, the REAL plane
-//   d_c[l] = 1/2 Im sum_{k in class c} Z[k]^2 e^{+2 pi i k l / P},   l in [0,64)^2,
+//   d_c[l] = Im sum_{k in class c} Z[k]^2 e^{+2 pi i k l / P},   l in [0,64)^2  (twice the
+//   class's share of the convolution; the readers scale by 1/(2 P^2)),
 // in LDS (real because each class is closed under k -> -k).  The full linear
 // convolution at index l in [0,127)^2 (lag = l - (n-1)) is
-//   conv[l] = P^-2 sum_c (-1)^(c . [l>=64]) d_c[l mod 64]
+//   conv[l] = (2 P^2)^-1 sum_c (-1)^(c . [l>=64]) d_c[l mod 64]
 // and its trigonometric interpolant (the upsample=U mode) is
-//   F(t)  = P^-2 sum_c sum_m K_cy(ty-my) d_c[m] K_cx(tx-mx),
+//   F(t)  = (2 P^2)^-1 sum_c sum_m K_cy(ty-my) d_c[m] K_cx(tx-mx),
 // two small real matrix products per class, done with v_mfma_f32_16x16x4_f32.
 //
 // This header is compiled by hipcc for gfx950 (spx_capi.hip) and, unchanged, by
@@ -514,12 +515,17 @@ SPX_DEVICE float fold_tile(cf (&v)[8][8]) {
 // Caller must have issued a block_sync after staging; ends with a block_sync.
 // ---------------------------------------------------------------------------
 template <int C, int DBG = 0>
-SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk) {
+SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, int rot = 0) {
     typedef Lds<C> L;
     static_assert(C == 2, "class decomposition implemented for P = 128");
     const int tid = fresh_tid();
-    const int wave = tid >> 6, lane = tid & 63;
-    const int cy = wave / C, cx = wave % C;       // this wave's parity class
+    const int lane = tid & 63;
+    // This wave's parity class.  Classes differ in twiddle work ((0,0) has none, (1,1) the
+    // most), so the pair kernel rotates the class <-> wave assignment from pair to pair
+    // (`rot`); exchange buffer, class plane and fine window are indexed by CLASS, so nothing
+    // downstream depends on which wave produced them.
+    const int wave = ((tid >> 6) + rot) & (C * C - 1);
+    const int cy = wave / C, cx = wave % C;
     const int l1 = lane >> 3, l0 = lane & 7;      // lane digits (y-ish, x-ish)
     const cf* tw = reinterpret_cast<const cf*>(lds + L::TW_OFF);
     const float* zre = reinterpret_cast<const float*>(lds + L::R_OFF);
@@ -624,7 +630,8 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk) {
     fft8_x<-1>(v);
     SPX_DBG_STOP(9);
     clk.tick(9);
-    // class post-twiddle conj(w_P^{8 (cy y1 + cx x1)}); half the imaginary part is kept.
+    // class post-twiddle conj(w_P^{8 (cy y1 + cx x1)}); the imaginary part is kept (the factor
+    // 1/2 of conv = Im(IFFT(Z^2))/2 is folded into the readers' output scale).
     // The plane goes into this wave's own exchange buffer (its reads above are done).
     float* plane = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::PLANE_STRIDE_BYTES);
     if (cy) {
@@ -642,7 +649,7 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk) {
         for (int y1 = 0; y1 < 8; ++y1) {
             const cf a = v[y1][x1];
             const int row = l1 + 8 * y1;
-            plane[row * L::PS + plane_col(row, l0 + 8 * x1)] = 0.5f * (a.y * wx.x - a.x * wx.y);  // Im(a conj w)/2
+            plane[row * L::PS + plane_col(row, l0 + 8 * x1)] = a.y * wx.x - a.x * wx.y;      // Im(a conj w)
         }
     }
     rt::block_sync_lds();
@@ -672,7 +679,7 @@ SPX_DEVICE float window_value(const unsigned char* lds, int ny, int nx, int qy, 
     // same association as coarse_argmax: d00 + fx d01 + fy (d10 + fx d11)
     const float fx = sx ? -1.0f : 1.0f, fy = sy ? -1.0f : 1.0f;
     const float acc = __builtin_fmaf(fy, __builtin_fmaf(fx, d[3], d[2]), __builtin_fmaf(fx, d[1], d[0]));
-    return acc * out_scale;     // out_scale = 1 / (P^2 bal)
+    return acc * out_scale;     // out_scale = 1 / (2 P^2 bal)
 }
 
 // ---------------------------------------------------------------------------
@@ -786,9 +793,9 @@ template <int WB> struct FineTables {
     f32x4 ky[WB][4], kx[WB][4];
 };
 template <int C, int WB>
-SPX_DEVICE void load_fine_tables(FineTables<WB>& ft, const float* __restrict__ ktab) {
+SPX_DEVICE void load_fine_tables(FineTables<WB>& ft, const float* __restrict__ ktab, int rot = 0) {
     const int tid = fresh_tid();
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = ((tid >> 6) + rot) & (C * C - 1), lane = tid & 63;     // class, see cc_planes
     const int cy = wave / C, cx = wave % C;
     ktab = rt::launder(ktab);
     // table slices of this lane: [2 (y|x)][2 (class)][WB][64 lanes][16]
@@ -805,12 +812,12 @@ SPX_DEVICE void load_fine_tables(FineTables<WB>& ft, const float* __restrict__ k
 
 template <int C, int WB>
 SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB>& ft,
-                            int ny, int nx, int qyc, int qxc) {
+                            int ny, int nx, int qyc, int qxc, int rot = 0) {
     typedef Lds<C> L;
     static_assert(C == 2, "");
     constexpr int W = 16 * WB;
     const int tid = fresh_tid();
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = ((tid >> 6) + rot) & (C * C - 1), lane = tid & 63;     // class, see cc_planes
     const int cy = wave / C, cx = wave % C;
     const int lk = lane >> 4, lj = lane & 15;
     const float* plane = reinterpret_cast<const float*>(lds + L::R_OFF + wave * L::PLANE_STRIDE_BYTES);
@@ -879,7 +886,7 @@ SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB>& ft,
                     f[bb][ab] = rt::mfma_16x16x4(sgn * ka[bb][r], acc[ab][t][r], f[bb][ab]);
         }
     }
-    const float scale = 1.0f / (float)(L::P * L::P);
+    const float scale = 0.5f / (float)(L::P * L::P);
     if constexpr (L::fb_count(W) == C * C) {
         // one window per class; the reader adds the four in fixed order (fine_value)
         float* mine = fbuf + wave * W * W;
@@ -1032,17 +1039,18 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
     rt::consume(warm);        // the warm-up load of this pair has landed (or was never issued)
     stage_pair<C>(lds, ref, img, ny, nx, ns, ssq);
     const float bal = balance_factor(scr, ssq);       // includes the barrier after staging
-    const float oscale = 1.0f / ((float)(L::P * L::P) * bal);
+    const float oscale = 0.5f / ((float)(L::P * L::P) * bal);
     clk.tick(0);
     if constexpr (DBG == 1) return;
-    if (cc_planes<C, DBG>(lds, bal, clk)) return;
+    const int rot = (C * C - fit_wave) & (C * C - 1);     // the fitting wave takes the lightest class (0,0)
+    if (cc_planes<C, DBG>(lds, bal, clk, rot)) return;
     if constexpr (DBG == 10) return;
     // pull the next pair into L2 while this one is in its tail
     if (next_ref) warm = warm_next_pair(next_ref, next_img);
 
     // the refine stage's constant operands: issue the loads now, use them after the arg-max
     FineTables<(WB > 0 ? WB : 1)> ft;
-    if constexpr (WB > 0) load_fine_tables<C, WB>(ft, ktab);
+    if constexpr (WB > 0) load_fine_tables<C, WB>(ft, ktab, rot);
     // coarse arg-max over the flipped 'same' window (centroid.py:114-116)
     float bv;
     int bi;
@@ -1063,7 +1071,7 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
         int imax = 0, jmax = 0;
         bool inside = false;
         for (int iter = 0; iter < 4; ++iter) {
-            fine_window<C, (WB > 0 ? WB : 1)>(lds, ft, ny, nx, qyc, qxc);
+            fine_window<C, (WB > 0 ? WB : 1)>(lds, ft, ny, nx, qyc, qxc, rot);
             clk.tick(12);
             if constexpr (DBG == 12) { if (tid == 0) out[0] = (double)fine_value<C, W>(lds, 0, 0); return; }
             // arg-max over the part of the window inside the virtual image: every wave scans
@@ -1186,7 +1194,7 @@ SPX_DEVICE void disp5_body(const float* __restrict__ ref, const float* __restric
         float ssq[2];
         stage_pair<C>(lds, ref, im4 + q * stride, ny, nx, ns, ssq);
         const float bal = balance_factor(scr, ssq);
-        const float oscale = 1.0f / ((float)(L::P * L::P) * bal);
+        const float oscale = 0.5f / ((float)(L::P * L::P) * bal);
         PhaseClock<0> noclk;
         cc_planes<C>(lds, bal, noclk);
         const int qx = tid & 63;
