@@ -49,8 +49,8 @@ def main():
         'hbm_bytes_per_launch': rd + wr,
         'algorithmic_bytes_per_launch': a.pairs * a.bytes_per_pair,
         'note': 'MI355X_MICROARCH.md (HBM): FETCH_SIZE counts half the bytes of wide coalesced reads on '
-                'gfx950 (doubled here); WRITE_SIZE exact.  Excess over the algorithmic bytes = scratch '
-                'traffic of the remaining spilled VGPRs + constant tables.',
+                'gfx950 (doubled here); WRITE_SIZE exact.  Excess over the algorithmic bytes = constant '
+                'tables and scratch traffic of spilled VGPRs, if the build has any.',
     }, indent=1))
 
 
