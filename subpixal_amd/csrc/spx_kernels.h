@@ -551,7 +551,7 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
         for (int y1 = 1; y1 < 8; ++y1) {
             const cf w = tw[8 * cy * y1];
 #pragma unroll
-            for (int x1 = 0; x1 < 8; ++x1) v[y1][x1] = cmul(v[y1][x1], w);
+            for (int x1 = 0; x1 < 8; ++x1) rt::cmul_ip(v[y1][x1], w);
         }
     }
     if (cx) {
@@ -559,7 +559,7 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
         for (int x1 = 1; x1 < 8; ++x1) {
             const cf w = tw[8 * cx * x1];
 #pragma unroll
-            for (int y1 = 0; y1 < 8; ++y1) v[y1][x1] = cmul(v[y1][x1], w);
+            for (int y1 = 0; y1 < 8; ++y1) rt::cmul_ip(v[y1][x1], w);
         }
     }
     fft8_y<1>(v);                           // y1 -> kyb
@@ -639,7 +639,7 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
         for (int y1 = 1; y1 < 8; ++y1) {
             const cf wy = tw[8 * cy * y1];
 #pragma unroll
-            for (int x1 = 0; x1 < 8; ++x1) v[y1][x1] = cmulc(v[y1][x1], wy);
+            for (int x1 = 0; x1 < 8; ++x1) rt::cmulc_ip(v[y1][x1], wy);
         }
     }
 #pragma unroll

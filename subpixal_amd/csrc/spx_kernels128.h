@@ -183,7 +183,7 @@ SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref
         for (int y1 = 1; y1 < 8; ++y1) {
             const cf w = tw[8 * cy * y1];
 #pragma unroll
-            for (int x1 = 0; x1 < 8; ++x1) v[y1][x1] = cmul(v[y1][x1], w);
+            for (int x1 = 0; x1 < 8; ++x1) rt::cmul_ip(v[y1][x1], w);
         }
     }
     if (cx) {
@@ -191,7 +191,7 @@ SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref
         for (int x1 = 1; x1 < 8; ++x1) {
             const cf w = tw[8 * cx * x1];
 #pragma unroll
-            for (int y1 = 0; y1 < 8; ++y1) v[y1][x1] = cmul(v[y1][x1], w);
+            for (int y1 = 0; y1 < 8; ++y1) rt::cmul_ip(v[y1][x1], w);
         }
     }
     fft8_y<1>(v);

@@ -101,6 +101,21 @@ SPX_DEVICE f32x2 cmulc(f32x2 a, f32x2 w) {
         : "=&v"(r) : "v"(a), "v"(w));
     return r;
 }
+// a *= w and a *= conj(w) IN PLACE (result in a's own registers, one scratch pair): used
+// where the multiply sits in a conditional block, so that no register permutation is
+// needed where the block re-joins the path that skipped it.
+SPX_DEVICE void cmul_ip(f32x2& a, f32x2 w) {
+    f32x2 t;
+    asm("v_pk_mul_f32 %1, %0, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %0, %2, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "+v"(a), "=&v"(t) : "v"(w));
+}
+SPX_DEVICE void cmulc_ip(f32x2& a, f32x2 w) {
+    f32x2 t;
+    asm("v_pk_mul_f32 %1, %0, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %0, %2, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "+v"(a), "=&v"(t) : "v"(w));
+}
 // s + (-i) d = (s.x + d.y, s.y - d.x)
 SPX_DEVICE f32x2 add_mi(f32x2 s, f32x2 d) {
     f32x2 r;

@@ -79,6 +79,8 @@ SPX_DEVICE void atomic_max_i32(int* p, int v) { int o = __atomic_load_n(p, __ATO
 SPX_DEVICE void atomic_add_i32(int* p, int v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 SPX_DEVICE f32x2 cmul(f32x2 a, f32x2 w) { return f32x2{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
 SPX_DEVICE f32x2 cmulc(f32x2 a, f32x2 w) { return f32x2{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y}; }
+SPX_DEVICE void cmul_ip(f32x2& a, f32x2 w) { a = cmul(a, w); }
+SPX_DEVICE void cmulc_ip(f32x2& a, f32x2 w) { a = cmulc(a, w); }
 SPX_DEVICE f32x2 add_mi(f32x2 s, f32x2 d) { return f32x2{s.x + d.y, s.y - d.x}; }
 SPX_DEVICE f32x2 add_pi(f32x2 s, f32x2 d) { return f32x2{s.x - d.y, s.y + d.x}; }
 SPX_DEVICE f32x2 neg_add_mi(f32x2 d) { return f32x2{d.y - d.x, -d.x - d.y}; }
