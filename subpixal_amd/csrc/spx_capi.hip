@@ -151,7 +151,13 @@ template <typename K> int allow_lds(K kernel, int bytes) {
 // workgroups per launch: enough to fill 256 CUs x 2 resident groups several times
 // over; the kernels grid-stride over the batch.
 unsigned grid_for(const DeviceTables* t, int64_t nbatch) {
-    const int64_t cap = (int64_t)t->num_cu * 32;
+    // SPX_GRID_PER_CU (tuning knob): workgroups launched per CU (2 are resident at a time)
+    static const int per_cu = [] {
+        const char* e = getenv("SPX_GRID_PER_CU");
+        const int v = e ? atoi(e) : 32;
+        return v >= 1 && v <= 1024 ? v : 32;
+    }();
+    const int64_t cap = (int64_t)t->num_cu * per_cu;
     return (unsigned)(nbatch < cap ? nbatch : cap);
 }
 
