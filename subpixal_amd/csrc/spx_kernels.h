@@ -1175,6 +1175,67 @@ SPX_TKERNEL(256) void pair_kernel(const float* __restrict__ ref, const float* __
 // half-pixel dithers, interlaced 2x image, arg-max, 5x5 fit on the 2x grid.
 // icc: float [2ny][2nx] per item in global memory (user output or workspace).
 // ---------------------------------------------------------------------------
+// One dither's flipped 'same' window -> its interlaced positions icc[2 qy + oy][2 qx + ox]
+// (cc.py:121-126), walking the class planes in storage order exactly like coarse_argmax
+// (16-byte LDS reads, 3 FMAs per element); (bv, bi) accumulate the arg-max over the
+// interlaced image (index = row-major position in it).
+template <int C>
+SPX_DEVICE void interlace_window(const unsigned char* lds, int ny, int nx, float out_scale,
+                                 float* __restrict__ icc, int ox, int oy, float& bv, int& bi) {
+    typedef Lds<C> L;
+    static_assert(C == 2, "");
+    const int tid = fresh_tid();
+    const int loy = (ny - 1) / 2, lox = (nx - 1) / 2;
+    const int NX = 2 * nx;
+    const float ninf = -__builtin_inff();
+    const int mx4 = (tid & 15) << 2;
+    int gx[4];
+    float fx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int mx = mx4 + e;
+        const bool wrap = mx < lox;
+        const int qx = (nx - 1) + lox - mx - (wrap ? 64 : 0);
+        gx[e] = qx >= 0 ? 2 * qx + ox : -1;
+        fx[e] = wrap ? -1.0f : 1.0f;
+    }
+    float val[4][4];
+    int rowbase[4];
+    float m = ninf;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int my = (tid >> 4) + 16 * i;
+        const bool wrap = my < loy;
+        const int qy = (ny - 1) + loy - my - (wrap ? 64 : 0);
+        const float fy = wrap ? -1.0f : 1.0f;
+        rowbase[i] = qy >= 0 ? (2 * qy + oy) * NX : -1;
+        f32x4 d[C * C];
+#pragma unroll
+        for (int c = 0; c < C * C; ++c)
+            d[c] = *reinterpret_cast<const f32x4*>(lds + L::R_OFF + c * L::PLANE_STRIDE_BYTES +
+                                                   (my * L::PS + plane_col(my, mx4)) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = __builtin_fmaf(fx[e], d[1][e], d[0][e]);
+            const float t = __builtin_fmaf(fx[e], d[3][e], d[2][e]);
+            const float v = __builtin_fmaf(fy, t, u) * out_scale;
+            const bool ok = rowbase[i] >= 0 && gx[e] >= 0;
+            if (ok) icc[rowbase[i] + gx[e]] = v;
+            val[i][e] = ok ? v : ninf;
+            m = __builtin_fmaxf(m, val[i][e]);
+        }
+    }
+    int best = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = (val[i][e] == m) ? rowbase[i] + gx[e] : 0x7fffffff;
+            best = idx < best ? idx : best;
+        }
+    if (better(m, best, bv, bi)) { bv = m; bi = best; }
+}
+
 template <int C>
 SPX_DEVICE void disp5_body(const float* __restrict__ ref, const float* __restrict__ im4,
                            int ny, int nx, int cc_type, const cf* __restrict__ tw_g,
@@ -1197,15 +1258,7 @@ SPX_DEVICE void disp5_body(const float* __restrict__ ref, const float* __restric
         const float oscale = 0.5f / ((float)(L::P * L::P) * bal);
         PhaseClock<0> noclk;
         cc_planes<C>(lds, bal, noclk);
-        const int qx = tid & 63;
-        if (qx < nx) {
-            for (int qy = tid >> 6; qy < ny; qy += kThreads / 64) {
-                const float val = window_value<C>(lds, ny, nx, qy, qx, oscale);
-                const int gi = (2 * qy + oy) * NX + 2 * qx + ox;
-                icc[gi] = val;
-                if (better(val, gi, bv, bi)) { bv = val; bi = gi; }
-            }
-        }
+        interlace_window<C>(lds, ny, nx, oscale, icc, ox, oy, bv, bi);
         rt::block_sync_lds();                    // planes are overwritten by the next stage
     }
     rt::block_sync();        // icc (GLOBAL memory) written above is read below by other waves
