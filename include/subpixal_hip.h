@@ -89,7 +89,7 @@ const char* spx_last_error(void);
  * Bytes of device scratch the batched calls need (0 when none).  Cutouts up to 64x64
  * are processed entirely in registers/LDS; larger ones (the 128 tile, FFT period 256)
  * keep per-workgroup class planes and the 256x256 convolution in an L2-resident
- * workspace of 768 KiB per resident workgroup (independent of nbatch beyond the grid).
+ * workspace of 772 KiB per resident workgroup (independent of nbatch beyond the grid).
  * For the reference mode `need_icc` adds room for the interlaced images when the
  * caller does not want them back (out_icc == NULL).
  */

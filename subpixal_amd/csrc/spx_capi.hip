@@ -122,10 +122,11 @@ int ktab32_for(DeviceTables* t, int upsample, const float** out) {
     return 0;
 }
 
-// workgroups of a 128-tile launch (each owns one 768 KiB workspace slot)
+// workgroups of a 128-tile launch (each owns one 772 KiB workspace slot)
 int64_t grid128(int num_cu, int64_t nbatch) {
     // SPX_GRID128_PER_CU (tuning knob, default 2): resident workgroups per CU; each owns
-    // 768 KiB of workspace, and the total should stay inside the 256 MiB Infinity Cache
+    // 772 KiB of workspace (at 2 per CU the total, 386 MiB, exceeds the 256 MiB Infinity Cache;
+    // 1 per CU fits but measured slower: too little latency hiding)
     static const int per_cu = [] {
         const char* e = getenv("SPX_GRID128_PER_CU");
         const int v = e ? atoi(e) : 2;

@@ -37,7 +37,8 @@ def test_argument_errors_without_gpu():
     assert lib.spx_workspace_bytes_displacement5(10, 64, 64, 1) == 10 * 4 * 64 * 64 * 4
     assert lib.spx_workspace_bytes_displacement5(10, 64, 64, 0) == 0
     assert lib.spx_workspace_bytes_xcorr(10, 64, 64) == 0
-    assert lib.spx_workspace_bytes_xcorr(10, 65, 64) == 10 * 768 * 1024
+    # 128 tile: 16 complex class planes of 64x64 + the 256 x (256+4) convolution, per workgroup
+    assert lib.spx_workspace_bytes_xcorr(10, 65, 64) == 10 * (16 * 2 * 64 * 64 + 256 * 260) * 4
     # argument validation happens before any HIP call
     assert lib.spx_xcorr_refine_f32(None, None, 1, 64, 64, 1, 0, None, None, None, 0, None) == -1
     assert lib.spx_xcorr_refine_f32(None, None, 0, 64, 64, 1, 0, None, None, None, 0, None) == 0
@@ -134,3 +135,24 @@ def test_sharded_driver_gloo_world2(tmp_path):
                          capture_output=True, text=True, env=env, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert 'GLOO_OK' in res.stdout
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    """include/subpixal_hip.h is the drop-in boundary: it must be usable from C (the language a
+    cgo / JNI / ctypes-free binding would consume), not only from C++."""
+    import re
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, 'include', 'subpixal_hip.h')).read()
+    names = sorted(set(re.findall(r'\b(spx_[a-z0-9_]+)\s*\(', header)))
+    assert len(names) >= 14
+    src = tmp_path / 'use_abi.c'
+    src.write_text('#include "subpixal_hip.h"\n'
+                   'const void* table[] = {\n' + ''.join('    (const void*)%s,\n' % n for n in names) + '};\n'
+                   'int abi(void) { return SPX_ABI_VERSION + SPX_MAX_SIDE + SPX_E_WORKSPACE + SPX_ST_FEWPTS; }\n')
+    subprocess.check_call([gcc, '-std=c99', '-Wall', '-Wextra', '-Werror', '-pedantic', '-Wno-pedantic',
+                           '-I', os.path.join(root, 'include'), '-c', str(src), '-o', str(tmp_path / 'use_abi.o')])
