@@ -27,7 +27,9 @@ extern "C" int emu_pair(const float* ref, const float* img, int64_t nbatch, int 
     if (wb > 0) kt = host::make_ktab(128, U, 16 * wb);
     const cf* twp = reinterpret_cast<const cf*>(tw.data());
     const float* ktp = kt.empty() ? nullptr : kt.data();
-    auto run = [&](auto fn) { rt::launch(g_grid > 0 && g_grid < nbatch ? g_grid : nbatch, kThreads, fn); };
+    auto run = [&](auto fn) {
+        rt::launch(g_grid > 0 && g_grid < nbatch ? g_grid : nbatch, kThreads, fn, Lds<2>::total(16 * wb));
+    };
     switch (wb) {
     case 0: run([&] { pair_kernel<2, 0>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
     case 1: run([&] { pair_kernel<2, 1>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
@@ -44,7 +46,8 @@ extern "C" int emu_disp5(const float* ref, const float* im4, int64_t nbatch, int
     std::vector<float> tw = host::make_twiddles(128);
     const cf* twp = reinterpret_cast<const cf*>(tw.data());
     rt::launch(nbatch, kThreads,
-               [&] { disp5_kernel<2>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status); });
+               [&] { disp5_kernel<2>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status); },
+               Lds<2>::total(0));
     return 0;
 }
 
@@ -54,7 +57,7 @@ extern "C" int emu_find_peak(const double* image, const uint8_t* mask, const dou
     if ((int64_t)wx * wy > kPeakMaxFitPoints) return -2;
     rt::launch(nbatch, kThreads, [&] {
         find_peak_kernel(image, mask, guess, nbatch, ny, nx, wx, wy, sbx, sby, out, status);
-    });
+    }, 0);
     return 0;
 }
 
@@ -89,7 +92,7 @@ extern "C" int emu_pair128(const float* ref, const float* img, int64_t nbatch, i
     const int64_t grid = g_grid > 0 && g_grid < nbatch ? g_grid : nbatch;
     std::vector<float> ws((size_t)grid * (kWs128Bytes / sizeof(float)));
     float* wsp = ws.data();
-    auto run = [&](auto fn) { rt::launch(grid, kThreads, fn); };
+    auto run = [&](auto fn) { rt::launch(grid, kThreads, fn, Lds128::total(16 * wb)); };
     switch (wb) {
     case 0: run([&] { pair128_kernel<0>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
     case 1: run([&] { pair128_kernel<1>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
@@ -109,21 +112,21 @@ extern "C" int emu_disp5_128(const float* ref, const float* im4, int64_t nbatch,
     float* wsp = ws.data();
     rt::launch(nbatch, kThreads, [&] {
         disp5_128_kernel(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, wsp);
-    });
+    }, Lds128::total(0));
     return 0;
 }
 
 extern "C" int emu_label_bboxes(const int32_t* seg, int fny, int fnx, int max_label, int32_t* boxes,
                                 int32_t* counts) {
-    rt::launch(1, 256, [&] { label_bbox_init_kernel(boxes, counts, max_label + 1); });
-    rt::launch(3, 256, [&] { label_bbox_kernel(seg, fny, fnx, max_label, boxes, counts); });
+    rt::launch(1, 256, [&] { label_bbox_init_kernel(boxes, counts, max_label + 1); }, 0);
+    rt::launch(3, 256, [&] { label_bbox_kernel(seg, fny, fnx, max_label, boxes, counts); }, 0);
     return 0;
 }
 
 extern "C" int emu_blot_affine4(const float* src, int64_t nbatch, int sny, int snx,
                                const double* affine, const float* gain, int ny, int nx, float* im4) {
     if (sny < 6 || snx < 6) return -2;
-    rt::launch(3, 256, [&] { blot_affine4_kernel(src, nbatch, sny, snx, affine, gain, ny, nx, im4); });
+    rt::launch(3, 256, [&] { blot_affine4_kernel(src, nbatch, sny, snx, affine, gain, ny, nx, im4); }, 0);
     return 0;
 }
 
@@ -139,7 +142,7 @@ extern "C" int emu_pair32(const float* ref, const float* img, int64_t nbatch, in
     const float* ktp = kt.empty() ? nullptr : kt.data();
     int64_t grid = (nbatch + 3) / 4;
     if (g_grid > 0 && g_grid < grid) grid = g_grid;
-    auto run = [&](auto fn) { rt::launch(grid, kThreads, fn); };
+    auto run = [&](auto fn) { rt::launch(grid, kThreads, fn, Lds32::total(16 * (wb > 0 ? wb : 1))); };
     switch (wb) {
     case 0: run([&] { pair32_kernel<0>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
     case 1: run([&] { pair32_kernel<1>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
@@ -157,6 +160,6 @@ extern "C" int emu_disp5_32(const float* ref, const float* im4, int64_t nbatch, 
     const cf* twp = reinterpret_cast<const cf*>(tw.data());
     rt::launch((nbatch + 3) / 4, kThreads, [&] {
         disp5_32_kernel(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status);
-    });
+    }, Lds32::total(16));
     return 0;
 }

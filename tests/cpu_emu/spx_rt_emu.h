@@ -10,6 +10,7 @@
 #include <barrier>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -37,7 +38,7 @@ struct WaveState {
 };
 
 struct EmuState {
-    alignas(16) unsigned char lds[160 * 1024];
+    unsigned char* lds = nullptr;     // one heap block of exactly the launch's dynamic LDS size
     std::unique_ptr<std::barrier<>> block_bar;
     std::vector<WaveState> waves;
     int nthreads = 0;
@@ -159,8 +160,16 @@ SPX_DEVICE f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
 
 // Run `body()` as a grid of `nblocks` workgroups of `nthreads` work-items,
 // one workgroup at a time.
-inline void launch(int64_t nblocks, int nthreads, const std::function<void()>& body) {
+// `lds_bytes`: the dynamic LDS size the real launch passes (spx_capi.hip).  The block is
+// allocated with exactly that size (rounded up to 16), so an address-sanitizer build of this
+// harness (make emu-asan) reports any kernel access beyond what the GPU launch provides.
+inline void launch(int64_t nblocks, int nthreads, const std::function<void()>& body,
+                   size_t lds_bytes = 160 * 1024) {
     EmuState& s = emu();
+    const size_t lds_alloc = (lds_bytes + 15) / 16 * 16;
+    std::unique_ptr<unsigned char, void (*)(void*)> lds_block(
+        static_cast<unsigned char*>(std::aligned_alloc(16, lds_alloc ? lds_alloc : 16)), std::free);
+    s.lds = lds_block.get();
     s.nthreads = nthreads;
     s.nblocks = nblocks;
     int nwaves = (nthreads + 63) / 64;
@@ -172,7 +181,7 @@ inline void launch(int64_t nblocks, int nthreads, const std::function<void()>& b
     }
     s.block_bar = std::make_unique<std::barrier<>>(nthreads);
     for (int64_t b = 0; b < nblocks; ++b) {
-        std::memset(s.lds, 0xCD, sizeof(s.lds));   // poison: LDS is uninitialised on a GPU
+        std::memset(s.lds, 0xCD, lds_alloc);       // poison: LDS is uninitialised on a GPU
         std::vector<std::thread> th;
         th.reserve(nthreads);
         for (int t = 0; t < nthreads; ++t) {

@@ -7,7 +7,9 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, 'tests', 'cpu_emu', 'libspx_emu.so')
+# SPX_EMU_LIB: another build of the same harness (tools/run_emu_asan.sh points it at the
+# address-sanitizer one)
+LIB = os.environ.get('SPX_EMU_LIB') or os.path.join(ROOT, 'tests', 'cpu_emu', 'libspx_emu.so')
 _fp = ctypes.POINTER(ctypes.c_float)
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -21,7 +23,8 @@ def lib():
         srcs = [os.path.join(ROOT, 'tests', 'cpu_emu', f) for f in ('emu_kernels.cpp', 'spx_rt_emu.h')]
         srcs += [os.path.join(ROOT, 'subpixal_amd', 'csrc', f)
                  for f in ('spx_kernels.h', 'spx_kernels128.h', 'spx_kernels32.h', 'spx_aux_kernels.h', 'spx_tables.h')]
-        if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+        if not os.environ.get('SPX_EMU_LIB') and (
+                not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs)):
             subprocess.check_call(['make', '-C', os.path.join(ROOT, 'subpixal_amd', 'csrc'), 'emu'])
         _lib = ctypes.CDLL(LIB)
     return _lib
