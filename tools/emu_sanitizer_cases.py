@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Kernel cases for the sanitizer builds of the CPU harness (tools/run_emu_asan.sh,
+tools/run_emu_tsan.sh): every tile and every refinement-window size, with several pairs per
+workgroup so that the waves run on across pair boundaries (the pair kernel has no barrier at
+the end of a pair).  Results are checked against the oracle as well."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import datagen                                         # noqa: E402
+import emu                                             # noqa: E402
+from oracle import subpixal_oracle as orc              # noqa: E402
+
+quick = '--quick' in sys.argv          # thread sanitizer: 10-20x slower, fewer window sizes
+cases = [(64, 6, 2, (1, 10) if quick else (1, 2, 10, 16, 20, 30, 43, 59)),
+         (50, 2, 1, () if quick else (27,)),
+         (32, 10, 1, (10,) if quick else (1, 10, 20, 43)),
+         (21, 5, 1, () if quick else (59,)),
+         (128, 2, 1, (2,) if quick else (1, 11, 20, 43)),
+         (97, 1, 1, () if quick else (59,))]
+for n, count, grid, ups in cases:
+    ref, img, truth = datagen.pair_batch(7, count, n)
+    for up in ups:
+        emu.set_grid(grid)
+        try:
+            got, st = emu.pair(ref, img, up)
+        finally:
+            emu.set_grid(0)
+        exp, est = orc.xcorr_refine_batch(ref, img, up)
+        err = float(np.abs(got - exp).max())
+        print('pair %3dx%-3d U=%-2d max |d| %.2e' % (n, n, up, err), flush=True)
+        assert np.array_equal(st, est) and err < 2e-3
+for n in (24, 48) if quick else (24, 48, 100):
+    r, m4, t = datagen.dither_batch(3, 2, n)
+    d, icc, st = emu.disp5(r, m4, 1)
+    e, est = orc.find_displacement_batch(r, m4, 'NCC')
+    print('find_displacement %3dx%-3d max |d| %.2e' % (n, n, float(np.abs(d - e).max())), flush=True)
+    assert np.abs(d - e).max() < 1e-4
+print('sanitizer cases OK')

@@ -10,3 +10,5 @@ cd "$ROOT"
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
 LD_PRELOAD="$RT" SPX_EMU_LIB="$ROOT/tests/cpu_emu/libspx_emu_asan.so" \
 python -m pytest tests/test_kernel_logic_cpu.py -x -q "$@"
+ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+LD_PRELOAD="$RT" SPX_EMU_LIB="$ROOT/tests/cpu_emu/libspx_emu_asan.so" python tools/emu_sanitizer_cases.py
