@@ -49,6 +49,17 @@ def _cpu_worker(args):
     return count, time.perf_counter() - t0
 
 
+def kernel_name(tile, upsample):
+    """Template instance the C-ABI dispatches to (spx_capi.hip): refinement-window blocks
+    WB = 0 for upsample 1, else ceil((upsample + 5) / 16)."""
+    wb = 0 if upsample == 1 else (upsample + 5 + 15) // 16
+    if tile <= 32:
+        return 'spx::pair32_kernel<%d>' % wb
+    if tile <= 64:
+        return 'spx::pair_kernel<2,%d>' % wb
+    return 'spx::pair128_kernel<%d>' % wb
+
+
 def usable_cores():
     """Host threads this process may really use: the cgroup CPU quota (the GPU box
     shows all 256 hardware threads but grants a share), else affinity/cpu_count."""
@@ -226,8 +237,7 @@ def main():
                 'traffic': traffic,
                 'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01/pmc_traffic.json)',
                 'algorithmic_bytes_per_launch': n_local * bytes_per_pair,
-                'kernel': ('spx::pair32_kernel<1>' if tile <= 32 else 'spx::pair_kernel<2,1>' if tile <= 64
-                           else 'spx::pair128_kernel<2>'),
+                'kernel': kernel_name(tile, args.upsample),
                 'kernel_ms': kern_ms,
                 'bytes_per_pair': bytes_per_pair,
                 'pairs_per_launch': n_local,

@@ -182,8 +182,10 @@ template <int C> struct Lds {
     static constexpr int FB_OFF = R_OFF + XCH_BYTES;        // fine windows
     static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     // fine window(s) of W x W floats sit behind the exchange region: one per class for
-    // W <= 32 (summed by the reader, one barrier), a single shared one above that
-    static constexpr int fb_count(int W) { return W <= 32 ? NCLS : 1; }
+    // W = 16 (summed by the reader, one barrier), a single shared one above that (summed by the
+    // writers in class order, four barriers) so that two workgroups still fit a CU's 160 KiB
+    // up to W = 48 (75.6 / 75.6 / 80.9 KiB; W = 64: 88 KiB, one workgroup per CU)
+    static constexpr int fb_count(int W) { return W <= 16 ? NCLS : 1; }
     static constexpr int total(int W) {
         return cmax(R_OFF + cmax(ZBUF_BYTES, XCH_BYTES), FB_OFF + fb_count(W) * W * W * 4);
     }
@@ -789,8 +791,15 @@ SPX_DEVICE PeakResult peak_from_argmax(unsigned char* lds_scr, int imax, int jma
 // into fbuf[b*W + a] (first index = x offset).
 // ---------------------------------------------------------------------------
 // the lane-constant K operands of one wave (loaded early, under the coarse arg-max)
+// Up to W = 32 they are held in registers; larger windows (upsample >= 28) fetch them from the
+// L2-resident table where they are used, or the 32 WB registers would spill.
 template <int WB> struct FineTables {
-    f32x4 ky[WB][4], kx[WB][4];
+    static constexpr bool kPreload = WB <= 2;
+    f32x4 ky[kPreload ? WB : 1][4], kx[kPreload ? WB : 1][4];
+    const f32x4* kty;
+    const f32x4* ktx;
+    SPX_DEVICE f32x4 y(int ab, int s4) const { return kPreload ? ky[ab][s4] : kty[ab * 64 * 4 + s4]; }
+    SPX_DEVICE f32x4 x(int bb, int t) const { return kPreload ? kx[bb][t] : ktx[bb * 64 * 4 + t]; }
 };
 template <int C, int WB>
 SPX_DEVICE void load_fine_tables(FineTables<WB>& ft, const float* __restrict__ ktab, int rot = 0) {
@@ -801,13 +810,17 @@ SPX_DEVICE void load_fine_tables(FineTables<WB>& ft, const float* __restrict__ k
     // table slices of this lane: [2 (y|x)][2 (class)][WB][64 lanes][16]
     const f32x4* kty = reinterpret_cast<const f32x4*>(ktab) + ((size_t)(0 * 2 + cy) * WB * 64 + lane) * 4;
     const f32x4* ktx = reinterpret_cast<const f32x4*>(ktab) + ((size_t)(1 * 2 + cx) * WB * 64 + lane) * 4;
+    ft.kty = kty;
+    ft.ktx = ktx;
+    if constexpr (FineTables<WB>::kPreload) {
 #pragma unroll
-    for (int b = 0; b < WB; ++b)
+        for (int b = 0; b < WB; ++b)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ft.ky[b][i] = kty[b * 64 * 4 + i];
-            ft.kx[b][i] = ktx[b * 64 * 4 + i];
-        }
+            for (int i = 0; i < 4; ++i) {
+                ft.ky[b][i] = kty[b * 64 * 4 + i];
+                ft.kx[b][i] = ktx[b * 64 * 4 + i];
+            }
+    }
 }
 
 template <int C, int WB>
@@ -849,7 +862,7 @@ SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB>& ft,
     for (int s4 = 0; s4 < 4; ++s4) {
         f32x4 kb[WB];
 #pragma unroll
-        for (int ab = 0; ab < WB; ++ab) kb[ab] = ft.ky[ab][s4];
+        for (int ab = 0; ab < WB; ++ab) kb[ab] = ft.y(ab, s4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int step = 4 * s4 + e;
@@ -874,7 +887,7 @@ SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB>& ft,
     for (int t = 0; t < 4; ++t) {
         f32x4 ka[WB];
 #pragma unroll
-        for (int bb = 0; bb < WB; ++bb) ka[bb] = ft.kx[bb][t];
+        for (int bb = 0; bb < WB; ++bb) ka[bb] = ft.x(bb, t);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = lxc + 16 * t + 4 * lk + r - 32;
