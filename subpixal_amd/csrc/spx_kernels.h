@@ -197,6 +197,7 @@ constexpr int SCR_INT = 64;       // int[16]   broadcast integers
 constexpr int SCR_RED_D = 128;    // double[4*4] per-wave double partials
 constexpr int SCR_FIT = 256;      // double[25] fit box values
 constexpr int SCR_STAT = 512;     // double[8]  statistics
+constexpr int SCR_RED_D6 = 576;   // double[4*6] per-wave partials of the six-value reduction (norm_stats)
 
 // ---------------------------------------------------------------------------
 // workgroup reductions
@@ -210,19 +211,21 @@ SPX_DEVICE double wave_sum(double v) {
 // sums NV doubles over the workgroup (fixed order: lanes by butterfly, waves
 // 0..3); every thread gets the totals.  Two barriers.
 template <int NV> SPX_DEVICE void block_sum(unsigned char* lds_scr, double (&v)[NV]) {
+    static_assert(NV <= 4 || NV == 6, "scratch slots exist for up to 4 values, or exactly 6");
+    constexpr int ST = NV <= 4 ? 4 : 6;
     const int tid = rt::thread_id();
-    double* part = reinterpret_cast<double*>(lds_scr + SCR_RED_D);
+    double* part = reinterpret_cast<double*>(lds_scr + (NV <= 4 ? SCR_RED_D : SCR_RED_D6));
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
     if ((tid & 63) == 0) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) part[(tid >> 6) * 4 + i] = v[i];
+        for (int i = 0; i < NV; ++i) part[(tid >> 6) * ST + i] = v[i];
     }
     rt::block_sync_lds();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         double s = 0.0;
-        for (int w = 0; w < kThreads / 64; ++w) s += part[w * 4 + i];
+        for (int w = 0; w < kThreads / 64; ++w) s += part[w * ST + i];
         v[i] = s;
     }
     rt::block_sync_lds();
@@ -700,8 +703,10 @@ SPX_DEVICE NormStats norm_stats(unsigned char* lds_scr, const float* __restrict_
     bool vec = (npx & 3) == 0 && (im_stride & 3) == 0 &&
                ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(ims)) & 15) == 0;
     const int nchunk = vec ? npx >> 2 : npx;        // loop units: float4 or float
-    // pass 1: counts and sums (pooled image pixels != 0; ref over the union mask)
-    double a[4] = {0.0, 0.0, 0.0, 0.0};   // n_im, sum_im, n_union, sum_ref
+    // ONE pass: counts, sums and sums of squares in float64 (pooled image pixels != 0; ref over
+    // the union mask).  numpy's std is the population form (ddof = 0) about the mean; in
+    // float64, sum(x^2)/n - mean^2 agrees with it to ~1e-16 * mean^2/var, far below float32.
+    double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // n_im, sum_im, sum_im^2, n_union, sum_ref, sum_ref^2
 #pragma unroll 2
     for (int i = tid; i < nchunk; i += kThreads) {
         f32x4 r4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -713,35 +718,26 @@ SPX_DEVICE NormStats norm_stats(unsigned char* lds_scr, const float* __restrict_
             else m4[0] = ims[q * im_stride + i];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (m4[e] != 0.0f) { a[0] += 1.0; a[1] += (double)m4[e]; anym |= 1u << e; }
+                if (m4[e] != 0.0f) {
+                    const double x = (double)m4[e];
+                    a[0] += 1.0; a[1] += x; a[2] += x * x; anym |= 1u << e;
+                }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (anym & (1u << e)) { a[2] += 1.0; a[3] += (double)r4[e]; }
+            if (anym & (1u << e)) {
+                const double x = (double)r4[e];
+                a[3] += 1.0; a[4] += x; a[5] += x * x;
+            }
     }
-    block_sum<4>(lds_scr, a);
-    const double im_mean = a[1] / a[0], ref_mean = a[3] / a[2];
-    const double n_im = a[0], n_un = a[2];
-    // pass 2: population variances about the true means (numpy std, ddof = 0)
-    double b[2] = {0.0, 0.0};
-#pragma unroll 2
-    for (int i = tid; i < nchunk; i += kThreads) {
-        f32x4 r4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        unsigned anym = 0;
-        if (vec) r4 = reinterpret_cast<const f32x4*>(ref)[i]; else r4[0] = ref[i];
-        for (int q = 0; q < npool; ++q) {
-            f32x4 m4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (vec) m4 = reinterpret_cast<const f32x4*>(ims + q * im_stride)[i];
-            else m4[0] = ims[q * im_stride + i];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (m4[e] != 0.0f) { const double d = (double)m4[e] - im_mean; b[0] += d * d; anym |= 1u << e; }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (anym & (1u << e)) { const double d = (double)r4[e] - ref_mean; b[1] += d * d; }
-    }
-    block_sum<2>(lds_scr, b);
+    block_sum<6>(lds_scr, a);
+    const double n_im = a[0], n_un = a[3];
+    const double im_mean = a[1] / n_im, ref_mean = a[4] / n_un;
+    double b[2];
+    b[0] = a[2] - a[1] * im_mean;       // sum (x - mean)^2 = sum x^2 - (sum x) mean
+    b[1] = a[5] - a[4] * ref_mean;
+    if (b[0] < 0.0) b[0] = 0.0;
+    if (b[1] < 0.0) b[1] = 0.0;
     ns.active = 1;
     const bool zero = (cc_type == CC_ZNCC);
     ns.im_mean = zero ? (float)im_mean : 0.0f;
