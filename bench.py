@@ -57,7 +57,7 @@ def kernel_name(tile, upsample):
         return 'spx::pair32_kernel<%d>' % wb
     if tile <= 64:
         return 'spx::pair_kernel<2,%d>' % wb
-    return 'spx::pair128_kernel<%d>' % wb
+    return 'spx::pair128_kernel<%d,%d>' % (3 if tile <= 96 else 4, wb)
 
 
 def usable_cores():

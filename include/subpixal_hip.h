@@ -87,9 +87,10 @@ const char* spx_last_error(void);
 
 /*
  * Bytes of device scratch the batched calls need (0 when none).  Cutouts up to 64x64
- * are processed entirely in registers/LDS; larger ones (the 128 tile, FFT period 256)
- * keep per-workgroup class planes and the 256x256 convolution in an L2-resident
- * workspace of 772 KiB per resident workgroup (independent of nbatch beyond the grid).
+ * are processed entirely in registers/LDS; larger ones (the 96 tile, FFT period 192, for
+ * 65..96 px and the 128 tile, period 256, above) keep per-workgroup class planes and the
+ * full convolution in an L2-resident workspace of 435 / 772 KiB per resident workgroup
+ * (independent of nbatch beyond the grid).  The reference mode uses the 128 tile above 64 px.
  * For the reference mode `need_icc` adds room for the interlaced images when the
  * caller does not want them back (out_icc == NULL).
  */
@@ -98,8 +99,8 @@ size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int nee
 
 /*
  * Pair mode.  ref, img: float32 [nbatch][ny][nx].  For every pair: linear
- * cross-correlation on the zero-padded grid (FFT period 64 / 128 / 256 for cutouts up to
- * 32 / 64 / 128 px per side: scipy's next_fast_len(2n-1)), arg-max over the flipped
+ * cross-correlation on the zero-padded grid (FFT period 64 / 128 / 192 / 256 for cutouts up
+ * to 32 / 64 / 96 / 128 px per side: scipy's next_fast_len(2n-1)), arg-max over the flipped
  * 'same' window, U-times trigonometric upsampling around it, 5x5 quadratic fit
  * (find_peak(., 5, 'all')), shift = peak/U - (n-1)//2.
  *   out_dxdy   : float64 [nbatch][2]  (dx, dy)

@@ -370,11 +370,15 @@ def find_displacement_batch(ref, im4, cc_type='NCC'):
 # Pair / upsample=U mode (not in the reference)
 # --------------------------------------------------------------------------
 def tile_size(ny, nx):
-    """Power-of-two tile T >= max(ny, nx), at least 32 (the tiles the HIP library
-    implements: 32, 64, 128).  The pair mode's FFT period is P = 2T (= scipy's
-    next_fast_len(2n-1) for n = 32, 64, 128)."""
-    t = 32
-    while t < max(ny, nx):
+    """Smallest tile T >= max(ny, nx) among the ones the HIP library implements: 32, 64,
+    96, 128.  The pair mode's FFT period is P = 2T (= scipy's next_fast_len(2n-1) for
+    n = 32, 64, 96, 128)."""
+    n = max(ny, nx)
+    for t in (32, 64, 96):
+        if n <= t:
+            return t
+    t = 128
+    while t < n:
         t *= 2
     return t
 

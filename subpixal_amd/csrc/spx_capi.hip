@@ -33,9 +33,11 @@ int hip_fail(hipError_t e, const char* what) {
 struct DeviceTables {
     spx::cf* tw128 = nullptr;                 // w_128^j
     spx::cf* tw256 = nullptr;                 // w_256^j (128 tile)
+    spx::cf* tw192 = nullptr;                 // w_192^j (96 tile)
     spx::cf* tw64 = nullptr;                  // w_64^j (32 tile)
     std::map<int, float*> ktab;               // upsample -> lane-major tables, 64 tile
     std::map<int, float*> ktab256;            // upsample -> lane-major tables, 128 tile
+    std::map<int, float*> ktab192;            // upsample -> lane-major tables, 96 tile
     std::map<int, float*> ktab32;             // upsample -> lane-major tables, 32 tile
     int num_cu = 256;
     bool lds_attr_set = false;
@@ -59,6 +61,10 @@ int current_tables(DeviceTables** out) {
         SPX_HIP(hipMalloc(&p, tw2.size() * sizeof(float)));
         SPX_HIP(hipMemcpy(p, tw2.data(), tw2.size() * sizeof(float), hipMemcpyHostToDevice));
         t.tw256 = reinterpret_cast<spx::cf*>(p);
+        std::vector<float> tw4 = spx::host::make_twiddles(192);
+        SPX_HIP(hipMalloc(&p, tw4.size() * sizeof(float)));
+        SPX_HIP(hipMemcpy(p, tw4.data(), tw4.size() * sizeof(float), hipMemcpyHostToDevice));
+        t.tw192 = reinterpret_cast<spx::cf*>(p);
         std::vector<float> tw3 = spx::host::make_twiddles(64);
         SPX_HIP(hipMalloc(&p, tw3.size() * sizeof(float)));
         SPX_HIP(hipMemcpy(p, tw3.data(), tw3.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -100,6 +106,23 @@ int ktab256_for(DeviceTables* t, int upsample, const float** out) {
         SPX_HIP(hipMalloc(&p, k.size() * sizeof(float)));
         SPX_HIP(hipMemcpy(p, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
         it = t->ktab256.emplace(upsample, reinterpret_cast<float*>(p)).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+int ktab192_for(DeviceTables* t, int upsample, const float** out) {
+    *out = nullptr;
+    const int wb = spx::host::window_blocks(upsample);
+    if (wb <= 0) return 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = t->ktab192.find(upsample);
+    if (it == t->ktab192.end()) {
+        std::vector<float> k = spx::host::make_ktab_big(192, upsample, 16 * wb);
+        void* p = nullptr;
+        SPX_HIP(hipMalloc(&p, k.size() * sizeof(float)));
+        SPX_HIP(hipMemcpy(p, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
+        it = t->ktab192.emplace(upsample, reinterpret_cast<float*>(p)).first;
     }
     *out = it->second;
     return 0;
@@ -191,16 +214,18 @@ int launch_pair32(const DeviceTables* t, const float* ref, const float* img, int
     return 0;
 }
 
-template <int WB, int DBG = 0>
+// C = 4: 128 tile (period 256), C = 3: 96 tile (period 192)
+template <int C, int WB, int DBG = 0>
 int launch_pair128(const DeviceTables* t, const float* ref, const float* img, int64_t nbatch, int ny,
                    int nx, int U, int cc_type, const float* ktab, double* out, int32_t* status,
                    float* ws, hipStream_t s) {
-    const int lds = spx::Lds128::total(16 * WB);
-    auto kern = spx::pair128_kernel<WB, DBG>;
+    const int lds = spx::LdsBig<C>::total(16 * WB);
+    auto kern = spx::pair128_kernel<C, WB, DBG>;
     int rc = allow_lds(kern, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid128(t->num_cu, nbatch)), dim3(spx::kThreads), lds, s,
-                       ref, img, nbatch, ny, nx, U, cc_type, t->tw256, ktab, out, status, ws);
+                       ref, img, nbatch, ny, nx, U, cc_type, C == 4 ? t->tw256 : t->tw192, ktab, out,
+                       status, ws);
     SPX_HIP(hipGetLastError());
     return 0;
 }
@@ -238,12 +263,19 @@ int spx_prepare(int upsample) {
 size_t spx_workspace_bytes_xcorr(int64_t nbatch, int ny, int nx) {
     if (nbatch <= 0 || ny <= 0 || nx <= 0) return 0;
     if (ny <= 64 && nx <= 64) return 0;
+    const size_t per_group = (ny <= 96 && nx <= 96) ? spx::kWs96Bytes : spx::kWs128Bytes;
+    return (size_t)grid128(device_cus(), nbatch) * per_group;
+}
+
+// the reference mode runs every cutout above 64 px on the 128 tile
+static size_t workspace_bytes_tile128(int64_t nbatch, int ny, int nx) {
+    if (nbatch <= 0 || (ny <= 64 && nx <= 64)) return 0;
     return (size_t)grid128(device_cus(), nbatch) * spx::kWs128Bytes;
 }
 
 size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int need_icc) {
     if (nbatch <= 0 || ny <= 0 || nx <= 0) return 0;
-    size_t b = spx_workspace_bytes_xcorr(nbatch, ny, nx);
+    size_t b = workspace_bytes_tile128(nbatch, ny, nx);
     if (need_icc) b += (size_t)nbatch * 4u * (size_t)ny * (size_t)nx * sizeof(float);
     return b;
 }
@@ -258,24 +290,37 @@ int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int
     const int wb = spx::host::window_blocks(upsample);
     if (wb < 0) return fail(SPX_E_SHAPE, "upsample must be in [1, 59]");
     if (nbatch == 0) return 0;
-    const bool big = ny > 64 || nx > 64;            // 128 tile, FFT period 256
+    const bool big = ny > 64 || nx > 64;            // 96 / 128 tile, FFT period 192 / 256
     if (big && (!workspace || workspace_bytes < spx_workspace_bytes_xcorr(nbatch, ny, nx)))
         return fail(SPX_E_WORKSPACE, "cutouts above 64 px need spx_workspace_bytes_xcorr() bytes");
     DeviceTables* t = nullptr;
     int rc = current_tables(&t);
     if (rc) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (big && ny <= 96 && nx <= 96) {
+        const float* ktab = nullptr;
+        rc = ktab192_for(t, upsample, &ktab);
+        if (rc) return rc;
+        float* ws = reinterpret_cast<float*>(workspace);
+        switch (wb) {
+        case 0: return launch_pair128<3, 0>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        case 1: return launch_pair128<3, 1>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        case 2: return launch_pair128<3, 2>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        case 3: return launch_pair128<3, 3>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        default: return launch_pair128<3, 4>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        }
+    }
     if (big) {
         const float* ktab = nullptr;
         rc = ktab256_for(t, upsample, &ktab);
         if (rc) return rc;
         float* ws = reinterpret_cast<float*>(workspace);
         switch (wb) {
-        case 0: return launch_pair128<0>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
-        case 1: return launch_pair128<1>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
-        case 2: return launch_pair128<2>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
-        case 3: return launch_pair128<3>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
-        default: return launch_pair128<4>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        case 0: return launch_pair128<4, 0>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        case 1: return launch_pair128<4, 1>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        case 2: return launch_pair128<4, 2>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        case 3: return launch_pair128<4, 3>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
+        default: return launch_pair128<4, 4>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
         }
     }
     const float* ktab = nullptr;
@@ -331,11 +376,11 @@ int spx_diag_pair128_phase(const float* ref, const float* img, int64_t nbatch, i
     DeviceTables* t = nullptr;
     int rc = current_tables(&t);
     if (rc) return rc;
-    if (workspace_bytes < spx_workspace_bytes_xcorr(nbatch, ny, nx)) return fail(SPX_E_WORKSPACE, "workspace");
+    if (workspace_bytes < workspace_bytes_tile128(nbatch, ny, nx)) return fail(SPX_E_WORKSPACE, "workspace");
     const float* ktab = nullptr;
     rc = ktab256_for(t, 20, &ktab);
     if (rc) return rc;
-    return launch_pair128<2, 100>(t, ref, img, nbatch, ny, nx, 20, 0, ktab, out_dxdy, out_status,
+    return launch_pair128<4, 2, 100>(t, ref, img, nbatch, ny, nx, 20, 0, ktab, out_dxdy, out_status,
                                   reinterpret_cast<float*>(workspace), reinterpret_cast<hipStream_t>(stream));
 }
 #endif
@@ -353,7 +398,7 @@ int spx_find_displacement5_f32(const float* ref, const float* im4, int64_t nbatc
     if (need > 0 && (!workspace || workspace_bytes < need))
         return fail(SPX_E_WORKSPACE, "workspace missing or smaller than spx_workspace_bytes_displacement5()");
     unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
-    const size_t tile_ws = spx_workspace_bytes_xcorr(nbatch, ny, nx);
+    const size_t tile_ws = workspace_bytes_tile128(nbatch, ny, nx);
     float* icc = out_icc ? out_icc : reinterpret_cast<float*>(wsb + tile_ws);
     DeviceTables* t = nullptr;
     int rc = current_tables(&t);

@@ -1,25 +1,28 @@
-// spx_kernels128.h -- the 128x128 tile (cutouts of 65..128 pixels per side;
-// BASELINE.json config 3): same path as spx_kernels.h, FFT period P = 256.
+// spx_kernels128.h -- the tiles above 64 pixels: 96x96 (cutouts of 65..96 pixels per side,
+// FFT period P = 192 = scipy's next_fast_len(2*96-1)) and 128x128 (97..128 pixels, P = 256;
+// BASELINE.json config 3).  Same path as spx_kernels.h, template parameter C = P / 64 (3 or 4).
 //
-// The padded spectrum splits into 16 classes  Z[4k'+c] = FFT64{ fold_c(z)[x'] w_P^(c x') },
-// fold_c(z)[x'] = z[x'] + (-i)^c z[x'+64]  (per axis), each again a 64x64 complex FFT done
-// by one wave in registers with the machinery of spx_kernels.h.  A workgroup (4 waves) runs
-// 4 rounds of 4 classes.  128x128 does not fit the LDS the way 64x64 does ("stresses LDS tile
-// sizing"), so the per-class results  g_c[l'] = sum_{k in c} Z[k]^2 e^{2 pi i k l'/P}  (complex,
-// 64x64) go to a per-workgroup workspace that stays in L2/MALL, a radix-4 pass combines them into
-// the full 256x256 real convolution  conv[l'+64s] = Im( sum_c i^(c.s) g_c[l'] ) / 2P^2  there, and
-// the arg-max, the MFMA refine (period-256 Dirichlet kernel, real) and the fit read from it.
+// The padded spectrum splits into C*C classes  Z[C k'+c] = FFT64{ fold_c(z)[x'] w_P^(c x') },
+// fold_c(z)[x'] = z[x'] + w_C^c z[x'+64], w_C = exp(-2 pi i / C)  (per axis; the cutout spans at
+// most two 64-blocks), each again a 64x64 complex FFT done by one wave in registers with the
+// machinery of spx_kernels.h.  A workgroup (4 waves) runs C rounds of C classes (for C = 3 the
+// fourth wave only helps staging).  These tiles do not fit the LDS the way 64x64 does ("stresses
+// LDS tile sizing"), so the per-class results  g_c[l'] = sum_{k in c} Z[k]^2 e^{2 pi i k l'/P}
+// (complex, 64x64) go to a per-workgroup workspace that stays in L2/MALL, a radix-C pass combines
+// them into the full PxP real convolution  conv[l'+64s] = Im( sum_c conj(w_C)^(c.s) g_c[l'] ) / 2P^2
+// there, and the arg-max, the MFMA refine (period-P Dirichlet kernel, real) and the fit read from it.
 //
-// Workspace per workgroup: 16 x 2 planes of 64x64 floats (512 KiB) + 256x260 floats (260 KiB).
+// Workspace per workgroup: C*C x 2 planes of 64x64 floats + P x (P+4) floats: 772 KiB (C = 4),
+// 435 KiB (C = 3).
 #pragma once
 
 namespace spx {
 
-struct Lds128 {
-    static constexpr int P = 256;
+template <int C> struct LdsBig {
+    static constexpr int P = 64 * C;
     static constexpr int ZS = 72, XS = 68;
-    static constexpr int TW_OFF = 0;                       // cf[256]
-    static constexpr int SCR_OFF = TW_OFF + P * 8;         // 1 KiB scratch
+    static constexpr int TW_OFF = 0;                       // cf[P]
+    static constexpr int SCR_OFF = TW_OFF + 256 * 8;       // 1 KiB scratch (table slot sized for P = 256)
     static constexpr int R_OFF = SCR_OFF + 1024;
     static constexpr int ZBUF_BYTES = 2 * 64 * ZS * 4;
     static constexpr int XCH_WAVE_BYTES = 64 * XS * 4;
@@ -30,12 +33,23 @@ struct Lds128 {
     static constexpr int total(int W) {
         return R_OFF + (XCH_BYTES > 4 * W * W * 4 ? XCH_BYTES : 4 * W * W * 4);
     }
+    // rows of the PxP convolution carry 4 extra columns that repeat columns 0..3, so that any
+    // 4 consecutive (circular) columns are contiguous in memory (fine_window_big's 16-byte loads)
+    static constexpr int CS = P + 4;
+    static constexpr size_t kPlaneFloats = 64 * 64;
+    static constexpr size_t kConvOffsetFloats = (size_t)C * C * 2 * kPlaneFloats;
+    static constexpr size_t kWsBytes = (kConvOffsetFloats + (size_t)P * CS) * sizeof(float);
+    // x mod P for x in [-P, 2P)
+    static SPX_DEVICE int wrap(int x) {
+        x += x < 0 ? P : 0;
+        x -= x >= P ? P : 0;
+        return x;
+    }
 };
+typedef LdsBig<4> Lds128;
 constexpr size_t kWs128PlaneFloats = 64 * 64;
-// rows of the 256x256 convolution carry 4 extra columns that repeat columns 0..3, so that any
-// 4 consecutive (circular) columns are contiguous in memory (fine_window128's 16-byte loads)
-constexpr int kConvStride128 = 256 + 4;
-constexpr size_t kWs128Bytes = (size_t)(16 * 2 * 64 * 64 + 256 * kConvStride128) * sizeof(float);
+constexpr size_t kWs128Bytes = LdsBig<4>::kWsBytes;
+constexpr size_t kWs96Bytes = LdsBig<3>::kWsBytes;
 struct __attribute__((packed, aligned(4))) F32x4U { float v[4]; };   // 16-byte load, 4-byte aligned
 
 // one 64x64 quadrant block (sy, sx) of z = ref + i*bal*flip(img), normalised, into LDS
@@ -134,15 +148,40 @@ SPX_DEVICE float balance128(unsigned char* scr, const float* __restrict__ ref,
     return balance_factor(scr, ssq);
 }
 
+// C = 3: v += w_3^M (staged block), w_3 = exp(-2 pi i / 3): one complex multiply by a constant;
+// one specialised copy of the element loop per factor (the case split stays outside the loop)
+template <int C, int M>
+SPX_DEVICE void fold_block128(cf (&v)[8][8], const float* zre, const float* zim, int l1, int l0) {
+    typedef LdsBig<C> L;
+    static_assert(C == 3 && M >= 0 && M <= 3, "");
+#pragma unroll
+    for (int y1 = 0; y1 < 8; ++y1)
+#pragma unroll
+        for (int x1 = 0; x1 < 8; ++x1) {
+            const int a = (l1 + 8 * y1) * L::ZS + l0 + 8 * x1;
+            const cf t = cf{zre[a], zim[a]};
+            cf& d = v[y1][x1];
+            if constexpr (M == 0) d = d + t;
+            else {
+                const cf w = cf{-0.5f, M == 1 ? -0.86602540378443865f : 0.86602540378443865f};
+                d = d + cmul(t, w);
+            }
+        }
+}
+
 // One round: classes (cy, cx = wave) of the staged pair -> complex planes in the workspace.
-template <int DBG>
+template <int C, int DBG>
 SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref,
                                const float* __restrict__ img, int ny, int nx, const NormStats& ns,
                                float bal, int cy, float* __restrict__ ws, PhaseClock<DBG>& clk) {
-    typedef Lds128 L;
+    typedef LdsBig<C> L;
+    static_assert(C == 3 || C == 4, "");
     const int tid = fresh_tid();
     const int wave = tid >> 6, lane = tid & 63;
-    const int cx = wave;
+    // C = 3: the fourth wave has no class of its own; it runs class (cy, 0) along (no divergent
+    // control flow around the FFT, which would cost registers) and only its stores are skipped
+    const bool active = C == 4 || wave < C;
+    const int cx = active ? wave : 0;
     const int l1 = lane >> 3, l0 = lane & 7;
     const cf* tw = reinterpret_cast<const cf*>(lds + L::TW_OFF);
     const float* zre = reinterpret_cast<const float*>(lds + L::R_OFF);
@@ -160,19 +199,30 @@ SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref
         if (any) stage_block128(lds, ref, img, ny, nx, sy, sx, ns, bal);
         rt::block_sync_lds();
         if (any) {
-            const int m = (cy * sy + cx * sx) & 3;
+            // d += w_C^m t,  w_C = exp(-2 pi i / C),  m = cy sy + cx sx
+            if constexpr (C == 4) {
+                // rotations by -i: the compiler turns this element-wise case split into
+                // compact code by itself (and spills if it is split by hand)
+                const int m = (cy * sy + cx * sx) & 3;
 #pragma unroll
-            for (int y1 = 0; y1 < 8; ++y1)
+                for (int y1 = 0; y1 < 8; ++y1)
 #pragma unroll
-                for (int x1 = 0; x1 < 8; ++x1) {
-                    const int a = (l1 + 8 * y1) * L::ZS + l0 + 8 * x1;
-                    const cf t = cf{zre[a], zim[a]};
-                    cf& d = v[y1][x1];
-                    if (m == 0) d = d + t;
-                    else if (m == 1) d = rt::add_mi(d, t);
-                    else if (m == 2) d = d - t;
-                    else d = rt::add_pi(d, t);
-                }
+                    for (int x1 = 0; x1 < 8; ++x1) {
+                        const int a = (l1 + 8 * y1) * L::ZS + l0 + 8 * x1;
+                        const cf t = cf{zre[a], zim[a]};
+                        cf& d = v[y1][x1];
+                        if (m == 0) d = d + t;
+                        else if (m == 1) d = rt::add_mi(d, t);
+                        else if (m == 2) d = d - t;
+                        else d = rt::add_pi(d, t);
+                    }
+            } else {
+                const int m = (cy * sy + cx * sx) % C;
+                if (m == 0) fold_block128<C, 0>(v, zre, zim, l1, l0);
+                else if (m == 1) fold_block128<C, 1>(v, zre, zim, l1, l0);
+                else if (m == 2) fold_block128<C, 2>(v, zre, zim, l1, l0);
+                else fold_block128<C, 3>(v, zre, zim, l1, l0);
+            }
         }
         rt::block_sync_lds();
     }
@@ -198,13 +248,13 @@ SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref
     fft8_x<1>(v);
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
-        const cf wy = tw[l1 * (cy + 4 * kb)];
+        const cf wy = tw[l1 * (cy + C * kb)];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[kb][j] = cmul(v[kb][j], wy);
     }
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
-        const cf wx = tw[l0 * (cx + 4 * kb)];
+        const cf wx = tw[l0 * (cx + C * kb)];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j][kb] = cmul(v[j][kb], wx);
     }
@@ -217,13 +267,13 @@ SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref
     fft8_x<-1>(v);
 #pragma unroll
     for (int y0 = 1; y0 < 8; ++y0) {          // y0 = 0: w^0
-        const cf wy = tw[y0 * (cy + 4 * l1)];
+        const cf wy = tw[y0 * (cy + C * l1)];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[y0][j] = cmulc(v[y0][j], wy);
     }
 #pragma unroll
     for (int x0 = 1; x0 < 8; ++x0) {          // x0 = 0: w^0
-        const cf wx = tw[x0 * (cx + 4 * l0)];
+        const cf wx = tw[x0 * (cx + C * l0)];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j][x0] = cmulc(v[j][x0], wx);
     }
@@ -243,7 +293,7 @@ SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref
     clk.tick(2);
     // g_c -> workspace planes [class][re|im][64][64], through the wave's LDS buffer so the
     // global stores are 16-byte, row-contiguous
-    float* g = ws + (size_t)((cy * 4 + cx) * 2) * kWs128PlaneFloats;
+    float* g = ws + (size_t)((cy * C + cx) * 2) * kWs128PlaneFloats;
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
 #pragma unroll
@@ -252,90 +302,109 @@ SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref
             for (int x1 = 0; x1 < 8; ++x1)
                 xch[(l1 + 8 * y1) * 64 + l0 + 8 * x1] = part ? v[y1][x1].y : v[y1][x1].x;
         rt::wave_sync();
+        if (active) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            reinterpret_cast<f32x4*>(g + part * kWs128PlaneFloats)[i * 64 + lane] =
-                reinterpret_cast<const f32x4*>(xch)[i * 64 + lane];
+            for (int i = 0; i < 16; ++i)
+                reinterpret_cast<f32x4*>(g + part * kWs128PlaneFloats)[i * 64 + lane] =
+                    reinterpret_cast<const f32x4*>(xch)[i * 64 + lane];
+        }
         rt::wave_sync();
     }
     clk.tick(3);
 }
 
-// radix-4 combination of the 16 class planes into the full real convolution:
-// conv[l'+64 s] = out_scale * Im( sum_c i^(cy sy + cx sx) g_c[l'] )
+// DFT-C with the inverse transform's sign along one class axis:  X[s] = sum_c conj(w_C)^(c s) a[c]
+template <int C> SPX_DEVICE void class_dft(const cf (&a)[C], cf (&x)[C]) {
+    if constexpr (C == 4) {
+        const cf e0 = a[0] + a[2], e1 = a[0] - a[2], o0 = a[1] + a[3], o1 = a[1] - a[3];
+        x[0] = e0 + o0;
+        x[2] = e0 - o0;
+        x[1] = rt::add_pi(e1, o1);      // e1 + i o1
+        x[3] = rt::add_mi(e1, o1);      // e1 - i o1
+    } else {
+        // conj(w_3) = -1/2 + i sqrt(3)/2:  X1,2 = a0 - (a1 + a2)/2 +- i (sqrt(3)/2)(a1 - a2)
+        const cf t1 = a[1] + a[2], t2 = a[1] - a[2];
+        const cf m = cf{a[0].x - 0.5f * t1.x, a[0].y - 0.5f * t1.y};
+        const cf n = cf{-0.86602540378443865f * t2.y, 0.86602540378443865f * t2.x};
+        x[0] = a[0] + t1;
+        x[1] = m + n;
+        x[2] = m - n;
+    }
+}
+
+// radix-C combination of the C*C class planes into the full real convolution:
+// conv[l'+64 s] = out_scale * Im( sum_c conj(w_C)^(cy sy + cx sx) g_c[l'] )
+template <int C>
 SPX_DEVICE void combine128(const float* __restrict__ ws, float* __restrict__ conv, float out_scale) {
+    typedef LdsBig<C> L;
     const int tid = fresh_tid();
     for (int i4 = tid; i4 < 64 * 64 / 4; i4 += kThreads) {          // 4 consecutive l'x per step
-        f32x4 gre[16], gim[16];
+        f32x4 gre[C * C], gim[C * C];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
+        for (int c = 0; c < C * C; ++c) {
             gre[c] = reinterpret_cast<const f32x4*>(ws + (size_t)(c * 2) * kWs128PlaneFloats)[i4];
             gim[c] = reinterpret_cast<const f32x4*>(ws + (size_t)(c * 2 + 1) * kWs128PlaneFloats)[i4];
         }
         const int ly = i4 >> 4, lx = (i4 & 15) << 2;
-        f32x4 o[4][4];                                               // [sy][sx]
+        f32x4 o[C][C];                                               // [sy][sx]
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            // DFT-4 with +i along cx, then along cy:  X[s] = sum_c i^(c s) a[c]
-            cf h[4][4];
+            cf h[C][C];                                              // [cy][sx]
 #pragma unroll
-            for (int cy = 0; cy < 4; ++cy) {
-                const cf a0 = cf{gre[cy * 4 + 0][e], gim[cy * 4 + 0][e]};
-                const cf a1 = cf{gre[cy * 4 + 1][e], gim[cy * 4 + 1][e]};
-                const cf a2 = cf{gre[cy * 4 + 2][e], gim[cy * 4 + 2][e]};
-                const cf a3 = cf{gre[cy * 4 + 3][e], gim[cy * 4 + 3][e]};
-                const cf e0 = a0 + a2, e1 = a0 - a2, o0 = a1 + a3, o1 = a1 - a3;
-                h[cy][0] = e0 + o0;
-                h[cy][2] = e0 - o0;
-                h[cy][1] = rt::add_pi(e1, o1);      // e1 + i o1
-                h[cy][3] = rt::add_mi(e1, o1);      // e1 - i o1
+            for (int cy = 0; cy < C; ++cy) {
+                cf a[C];
+#pragma unroll
+                for (int cx = 0; cx < C; ++cx) a[cx] = cf{gre[cy * C + cx][e], gim[cy * C + cx][e]};
+                class_dft<C>(a, h[cy]);
             }
 #pragma unroll
-            for (int sx = 0; sx < 4; ++sx) {
-                const cf a0 = h[0][sx], a1 = h[1][sx], a2 = h[2][sx], a3 = h[3][sx];
-                const cf e0 = a0 + a2, e1 = a0 - a2, o0 = a1 + a3, o1 = a1 - a3;
-                o[0][sx][e] = out_scale * (e0.y + o0.y);
-                o[2][sx][e] = out_scale * (e0.y - o0.y);
-                o[1][sx][e] = out_scale * rt::add_pi(e1, o1).y;
-                o[3][sx][e] = out_scale * rt::add_mi(e1, o1).y;
+            for (int sx = 0; sx < C; ++sx) {
+                cf a[C], x[C];
+#pragma unroll
+                for (int cy = 0; cy < C; ++cy) a[cy] = h[cy][sx];
+                class_dft<C>(a, x);
+#pragma unroll
+                for (int sy = 0; sy < C; ++sy) o[sy][sx][e] = out_scale * x[sy].y;
             }
         }
 #pragma unroll
-        for (int sy = 0; sy < 4; ++sy)
+        for (int sy = 0; sy < C; ++sy)
 #pragma unroll
-            for (int sx = 0; sx < 4; ++sx) {
-                float* row = conv + (size_t)(ly + 64 * sy) * kConvStride128;
+            for (int sx = 0; sx < C; ++sx) {
+                float* row = conv + (size_t)(ly + 64 * sy) * L::CS;
                 *reinterpret_cast<f32x4*>(row + lx + 64 * sx) = o[sy][sx];
-                if (sx == 0 && lx == 0) *reinterpret_cast<f32x4*>(row + 256) = o[sy][sx];   // wrap copy
+                if (sx == 0 && lx == 0) *reinterpret_cast<f32x4*>(row + L::P) = o[sy][sx];   // wrap copy
             }
     }
 }
 
-// cutout pair -> full 256x256 convolution in the workspace (ends with a full barrier)
-template <int DBG>
+// cutout pair -> full PxP convolution in the workspace (ends with a full barrier)
+template <int C, int DBG>
 SPX_DEVICE void conv_full128(unsigned char* lds, const float* __restrict__ ref,
                              const float* __restrict__ img, int ny, int nx, const NormStats& ns,
                              float* __restrict__ ws, PhaseClock<DBG>& clk) {
-    typedef Lds128 L;
+    typedef LdsBig<C> L;
     unsigned char* scr = lds + L::SCR_OFF;
     const float bal = balance128(scr, ref, img, ny, nx, ns);
     clk.tick(0);
-    for (int cy = 0; cy < 4; ++cy) class_round128<DBG>(lds, ref, img, ny, nx, ns, bal, cy, ws, clk);
+    for (int cy = 0; cy < C; ++cy) class_round128<C, DBG>(lds, ref, img, ny, nx, ns, bal, cy, ws, clk);
     rt::block_sync();                    // class planes (global) visible to every wave
     // conv = Im(IFFT(Z^2)) / 2, IFFT normalisation 1/P^2, balance undone
     const float out_scale = 0.5f / ((float)(L::P) * (float)(L::P) * bal);
-    combine128(ws, ws + 32 * kWs128PlaneFloats, out_scale);
+    combine128<C>(ws, ws + L::kConvOffsetFloats, out_scale);
     rt::block_sync();
     clk.tick(4);
 }
 
+template <int C>
 SPX_DEVICE float window_value128(const float* __restrict__ conv, int ny, int nx, int qy, int qx) {
-    return conv[(size_t)conv_index(ny, qy) * kConvStride128 + conv_index(nx, qx)];
+    return conv[(size_t)conv_index(ny, qy) * LdsBig<C>::CS + conv_index(nx, qx)];
 }
 
 // coarse arg-max over the flipped 'same' window (cutouts up to 128x128): the window is rows
 // [loy, loy+ny) x columns [lox, lox+nx) of the convolution, walked in storage order with
 // 16-byte loads; q = (n-1) + lo - l (conv_index inverted).
+template <int C>
 SPX_DEVICE void coarse_argmax128(const float* __restrict__ conv, int ny, int nx, float& bv, int& bi) {
     const int tid = fresh_tid();
     bv = -__builtin_inff();
@@ -348,7 +417,7 @@ SPX_DEVICE void coarse_argmax128(const float* __restrict__ conv, int ny, int nx,
     for (int g = tid; g < total; g += kThreads) {
         const int ry = g / nchunk, ch = g - ry * nchunk;
         const int ly = loy + ry, lx4 = (c4lo + ch) << 2;
-        const f32x4 d = *reinterpret_cast<const f32x4*>(conv + (size_t)ly * kConvStride128 + lx4);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(conv + (size_t)ly * LdsBig<C>::CS + lx4);
         const int qy = (ny - 1) + loy - ly;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -359,46 +428,52 @@ SPX_DEVICE void coarse_argmax128(const float* __restrict__ conv, int ny, int nx,
     }
 }
 
-// Fine window around flipped coarse index (qyc, qxc) by MFMA, period-256 real kernel
-//   K(t) = 1/256 [1 + 2 sum_{j=1..127} cos(2 pi j t / 256) + cos(pi t)].
-// Wave w contracts all 256 rows for the 64 window columns mx'' in [64 w - 128, 64 w - 64) and
-// leaves its partial window in its own LDS buffer; the reader adds the four (fine_value128).
-// Inside the wave, A-row lj of column tile t is column 64 w + 4 lj + t, so that a lane's four
-// tiles are 4 consecutive columns = ONE 16-byte load per row (64 per lane instead of 256
-// 4-byte ones); accumulator register r of tile t is then column 64 w + 16 lk + 4 r + t.
-// Tables (spx_tables.h make_ktab256), lane = 16 lk + lj:
-//   [0][blk][lane][s]       = K(-(16 blk + lj - W/2)/U - (4 s + lk - 128)),      s in [0,64)
-//   [1][blk][lane][4 T + r] = K(-(16 blk + lj - W/2)/U - (64 w + 16 lk + 4 r + t - 128)), T = 4 w + t
-template <int WB>
+// Fine window around flipped coarse index (qyc, qxc) by MFMA, period-P real kernel
+//   K(t) = 1/P [1 + 2 sum_{j=1..P/2-1} cos(2 pi j t / P) + cos(pi t)].
+// Wave w < C contracts all P rows for the 64 window columns mx'' in [64 w - P/2, 64 w - P/2 + 64)
+// and leaves its partial window in its own LDS buffer; the reader adds the four (fine_value128;
+// for C = 3 the fourth wave leaves zeros).  Inside the wave, A-row lj of column tile t is column
+// 64 w + 4 lj + t, so that a lane's four tiles are 4 consecutive columns = ONE 16-byte load per
+// row (P/4 per lane instead of P 4-byte ones); accumulator register r of tile t is then column
+// 64 w + 16 lk + 4 r + t.  Tables (spx_tables.h make_ktab_big), lane = 16 lk + lj:
+//   [0][blk][lane][s]       = K(-(16 blk + lj - W/2)/U - (4 s + lk - P/2)),       s in [0, P/4)
+//   [1][blk][lane][4 T + r] = K(-(16 blk + lj - W/2)/U - (64 w + 16 lk + 4 r + t - P/2)), T = 4 w + t
+template <int C, int WB>
 SPX_DEVICE void fine_window128(unsigned char* lds, const float* __restrict__ ktab,
                                const float* __restrict__ conv, int ny, int nx, int qyc, int qxc) {
-    typedef Lds128 L;
+    typedef LdsBig<C> L;
     constexpr int W = 16 * WB;
+    constexpr int NQ = L::P / 16;            // 16-byte table entries per (block, lane)
     const int tid = fresh_tid();
     const int wave = tid >> 6, lane = tid & 63;
     const int lk = lane >> 4, lj = lane & 15;
     float* fbuf = reinterpret_cast<float*>(lds + L::FB_OFF) + wave * W * W;
+    if (wave >= C) {                         // C = 3: nothing to contract, contribute zeros
+        for (int i = lane; i < W * W; i += 64) fbuf[i] = 0.0f;
+        rt::block_sync_lds();
+        return;
+    }
     const int lyc = conv_index(ny, qyc), lxc = conv_index(nx, qxc);
     ktab = rt::launder(ktab);
-    const f32x4* kty = reinterpret_cast<const f32x4*>(ktab) + (size_t)lane * 16;
-    const f32x4* ktx = reinterpret_cast<const f32x4*>(ktab) + (size_t)(WB * 64 + lane) * 16;
+    const f32x4* kty = reinterpret_cast<const f32x4*>(ktab) + (size_t)lane * NQ;
+    const f32x4* ktx = reinterpret_cast<const f32x4*>(ktab) + (size_t)(WB * 64 + lane) * NQ;
 
     f32x4 acc[WB][4];
 #pragma unroll
     for (int ab = 0; ab < WB; ++ab)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[ab][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int col0 = (lxc + 64 * wave + 4 * lj - 128) & 255;     // + t, t = 0..3 (wrap copy in the row)
+    const int col0 = L::wrap(lxc + 64 * wave + 4 * lj - L::P / 2);     // + t, t = 0..3 (wrap copy in the row)
 #pragma unroll 4
-    for (int s4 = 0; s4 < 16; ++s4) {
+    for (int s4 = 0; s4 < NQ; ++s4) {
         f32x4 kb[WB];
 #pragma unroll
-        for (int ab = 0; ab < WB; ++ab) kb[ab] = kty[(size_t)ab * 64 * 16 + s4];
+        for (int ab = 0; ab < WB; ++ab) kb[ab] = kty[(size_t)ab * 64 * NQ + s4];
         F32x4U a4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int row = (lyc + 4 * (4 * s4 + e) + lk - 128) & 255;
-            a4[e] = *reinterpret_cast<const F32x4U*>(conv + (size_t)row * kConvStride128 + col0);
+            const int row = L::wrap(lyc + 4 * (4 * s4 + e) + lk - L::P / 2);
+            a4[e] = *reinterpret_cast<const F32x4U*>(conv + (size_t)row * L::CS + col0);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -417,7 +492,7 @@ SPX_DEVICE void fine_window128(unsigned char* lds, const float* __restrict__ kta
     for (int t = 0; t < 4; ++t) {
         f32x4 ka[WB];
 #pragma unroll
-        for (int bb = 0; bb < WB; ++bb) ka[bb] = ktx[(size_t)bb * 64 * 16 + 4 * wave + t];
+        for (int bb = 0; bb < WB; ++bb) ka[bb] = ktx[(size_t)bb * 64 * NQ + 4 * wave + t];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -437,7 +512,7 @@ SPX_DEVICE void fine_window128(unsigned char* lds, const float* __restrict__ kta
 }
 
 template <int W> SPX_DEVICE float fine_value128(const unsigned char* lds, int b, int a) {
-    const float* fbuf = reinterpret_cast<const float*>(lds + Lds128::FB_OFF);
+    const float* fbuf = reinterpret_cast<const float*>(lds + LdsBig<4>::FB_OFF);   // same offset for every C
     float acc = fbuf[b * W + a];
 #pragma unroll
     for (int w = 1; w < 4; ++w) acc += fbuf[w * W * W + b * W + a];
@@ -447,31 +522,31 @@ template <int W> SPX_DEVICE float fine_value128(const unsigned char* lds, int b,
 // ---------------------------------------------------------------------------
 // pair mode, 128 tile
 // ---------------------------------------------------------------------------
-template <int WB, int DBG>
+template <int C, int WB, int DBG>
 SPX_DEVICE void pair128_body(const float* __restrict__ ref, const float* __restrict__ img, int ny,
                              int nx, int U, int cc_type, const float* __restrict__ ktab,
                              double* __restrict__ out, int* __restrict__ status,
                              unsigned char* lds, float* __restrict__ ws, PhaseClock<DBG>& clk) {
-    typedef Lds128 L;
+    typedef LdsBig<C> L;
     ny = rt::launder_uniform(ny);
     nx = rt::launder_uniform(nx);
     U = rt::launder_uniform(U);
     const int tid = fresh_tid();
     unsigned char* scr = lds + L::SCR_OFF;
     const NormStats ns = norm_stats(scr, ref, img, 1, 0, ny, nx, cc_type);
-    conv_full128<DBG>(lds, ref, img, ny, nx, ns, ws, clk);
-    const float* conv = ws + 32 * kWs128PlaneFloats;
+    conv_full128<C, DBG>(lds, ref, img, ny, nx, ns, ws, clk);
+    const float* conv = ws + L::kConvOffsetFloats;
 
     float bv;
     int bi;
-    coarse_argmax128(conv, ny, nx, bv, bi);
+    coarse_argmax128<C>(conv, ny, nx, bv, bi);
     block_argmax(scr, bv, bi, 0);
     int qyc = bi / nx, qxc = bi - (bi / nx) * nx;
     clk.tick(5);
     PeakResult pk;
     if constexpr (WB == 0) {
         pk = peak_fit_wave0(scr, qxc, qyc, nx, ny, [&](int x, int y) {
-            return window_value128(conv, ny, nx, y, x);
+            return window_value128<C>(conv, ny, nx, y, x);
         });
     } else {
         constexpr int W = 16 * (WB > 0 ? WB : 1);
@@ -479,7 +554,7 @@ SPX_DEVICE void pair128_body(const float* __restrict__ ref, const float* __restr
         int imax = 0, jmax = 0;
         bool inside = false;
         for (int iter = 0; iter < 4; ++iter) {
-            fine_window128<(WB > 0 ? WB : 1)>(lds, ktab, conv, ny, nx, qyc, qxc);
+            fine_window128<C, (WB > 0 ? WB : 1)>(lds, ktab, conv, ny, nx, qyc, qxc);
             clk.tick(6);
             const int fx0 = U * qxc - W / 2, fy0 = U * qyc - W / 2;
             float fv = -__builtin_inff();
@@ -528,26 +603,26 @@ SPX_DEVICE void pair128_body(const float* __restrict__ ref, const float* __restr
     clk.tick(8);
 }
 
-SPX_DEVICE void load_twiddles128(unsigned char* lds, const cf* __restrict__ tw_g) {
-    cf* tw = reinterpret_cast<cf*>(lds + Lds128::TW_OFF);
-    for (int i = rt::thread_id(); i < Lds128::P; i += kThreads) tw[i] = tw_g[i];
+template <int C> SPX_DEVICE void load_twiddles128(unsigned char* lds, const cf* __restrict__ tw_g) {
+    cf* tw = reinterpret_cast<cf*>(lds + LdsBig<C>::TW_OFF);
+    for (int i = rt::thread_id(); i < LdsBig<C>::P; i += kThreads) tw[i] = tw_g[i];
     rt::block_sync_lds();
 }
 
-template <int WB, int DBG = 0>
+template <int C, int WB, int DBG = 0>
 SPX_TKERNEL(256) void pair128_kernel(const float* __restrict__ ref, const float* __restrict__ img,
                                      int64_t nbatch, int ny, int nx, int U, int cc_type,
                                      const cf* __restrict__ tw_g, const float* __restrict__ ktab,
                                      double* __restrict__ out, int* __restrict__ status,
                                      float* __restrict__ workspace) {
     SPX_DYN_LDS(lds);
-    load_twiddles128(lds, tw_g);
-    float* ws = workspace + (size_t)rt::block_id() * (kWs128Bytes / sizeof(float));
+    load_twiddles128<C>(lds, tw_g);
+    float* ws = workspace + (size_t)rt::block_id() * (LdsBig<C>::kWsBytes / sizeof(float));
     const int64_t stride = (int64_t)ny * nx;
     PhaseClock<DBG> clk;
     clk.start();
     for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
-        pair128_body<WB, DBG>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, ktab, out + 2 * p,
+        pair128_body<C, WB, DBG>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, ktab, out + 2 * p,
                               status ? status + p : nullptr, lds, ws, clk);
         rt::block_sync();
         clk.tick(9);
@@ -567,9 +642,9 @@ SPX_TKERNEL(256) void disp5_128_kernel(const float* __restrict__ ref, const floa
                                        float* __restrict__ workspace) {
     typedef Lds128 L;
     SPX_DYN_LDS(lds);
-    load_twiddles128(lds, tw_g);
+    load_twiddles128<4>(lds, tw_g);
     float* ws = workspace + (size_t)rt::block_id() * (kWs128Bytes / sizeof(float));
-    const float* conv = ws + 32 * kWs128PlaneFloats;
+    const float* conv = ws + L::kConvOffsetFloats;
     unsigned char* scr = lds + L::SCR_OFF;
     const int64_t stride = (int64_t)ny * nx;
     const int NX = 2 * nx, NY = 2 * ny;
@@ -584,11 +659,11 @@ SPX_TKERNEL(256) void disp5_128_kernel(const float* __restrict__ ref, const floa
         PhaseClock<0> clk;
         for (int q = 0; q < 4; ++q) {
             const int ox = q & 1, oy = q >> 1;
-            conv_full128<0>(lds, r, m4 + q * stride, ny, nx, ns, ws, clk);
+            conv_full128<4, 0>(lds, r, m4 + q * stride, ny, nx, ns, ws, clk);
             const int qx = tid & 127;
             if (qx < nx) {
                 for (int qy = tid >> 7; qy < ny; qy += kThreads / 128) {
-                    const float val = window_value128(conv, ny, nx, qy, qx);
+                    const float val = window_value128<4>(conv, ny, nx, qy, qx);
                     const int gi = (2 * qy + oy) * NX + 2 * qx + ox;
                     icc[gi] = val;
                     if (better(val, gi, bv, bi)) { bv = val; bi = gi; }

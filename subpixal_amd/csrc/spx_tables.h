@@ -90,30 +90,32 @@ inline std::vector<float> make_ktab32(int U, int W) {
 }
 
 // Period-256 real interpolation kernel (128 tile) and its lane-major MFMA tables
-// (spx_kernels128.h fine_window128):
-//   [0][blk][lane][s]       = K(-(16 blk + lj - W/2)/U - (4 s + lk - 128)),        s in [0,64)
-//   [1][blk][lane][4 T + r] = K(-(16 blk + lj - W/2)/U - (64 w + 16 lk + 4 r + t - 128)), T = 4 w + t
-inline double kernel256(double t) {
+// (spx_kernels128.h fine_window128), P = 192 or 256:
+//   [0][blk][lane][s]       = K(-(16 blk + lj - W/2)/U - (4 s + lk - P/2)),        s in [0,P/4)
+//   [1][blk][lane][4 T + r] = K(-(16 blk + lj - W/2)/U - (64 w + 16 lk + 4 r + t - P/2)), T = 4 w + t
+inline double kernel_big(int P, double t) {
     double s = 1.0 + std::cos(kPi * t);
-    for (int k = 1; k < 128; ++k) s += 2.0 * std::cos(2.0 * kPi * k * t / 256.0);
-    return s / 256.0;
+    for (int k = 1; k < P / 2; ++k) s += 2.0 * std::cos(2.0 * kPi * k * t / (double)P);
+    return s / (double)P;
 }
-inline std::vector<float> make_ktab256(int U, int W) {
-    const int blocks = W / 16;
-    std::vector<float> k((size_t)2 * blocks * 64 * 64);
+// P = 192 (96 tile) or 256 (128 tile); P/4 entries per (part, block, lane)
+inline std::vector<float> make_ktab_big(int P, int U, int W) {
+    const int blocks = W / 16, n = P / 4;
+    std::vector<float> k((size_t)2 * blocks * 64 * n);
     for (int which = 0; which < 2; ++which)
         for (int blk = 0; blk < blocks; ++blk)
             for (int lane = 0; lane < 64; ++lane)
-                for (int i = 0; i < 64; ++i) {
+                for (int i = 0; i < n; ++i) {
                     const int lk = lane >> 4, lj = lane & 15;
                     // [1]: i = 4 T + r, T = 4 w + t  ->  column 64 w + 16 lk + 4 r + t
-                    const int m = which == 0 ? (4 * i + lk - 128)
-                                             : (64 * (i >> 4) + 16 * lk + 4 * (i & 3) + ((i >> 2) & 3) - 128);
+                    const int m = which == 0 ? (4 * i + lk - P / 2)
+                                             : (64 * (i >> 4) + 16 * lk + 4 * (i & 3) + ((i >> 2) & 3) - P / 2);
                     const double t = -(double)(16 * blk + lj - W / 2) / (double)U - (double)m;
-                    k[(((size_t)which * blocks + blk) * 64 + lane) * 64 + i] = (float)kernel256(t);
+                    k[(((size_t)which * blocks + blk) * 64 + lane) * n + i] = (float)kernel_big(P, t);
                 }
     return k;
 }
+inline std::vector<float> make_ktab256(int U, int W) { return make_ktab_big(256, U, W); }
 
 }  // namespace host
 }  // namespace spx

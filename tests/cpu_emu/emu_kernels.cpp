@@ -79,28 +79,40 @@ extern "C" int emu_gen_pairs(uint64_t seed, int64_t first, int64_t nbatch, int n
     return 0;
 }
 
-extern "C" int emu_pair128(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
-                           int U, int cc_type, double* out, int* status) {
-    if (ny < 5 || nx < 5 || ny > 128 || nx > 128) return -1;
+template <int C>
+static int emu_pair_big(const float* ref, const float* img, int64_t nbatch, int ny, int nx, int U,
+                        int cc_type, double* out, int* status) {
     const int wb = host::window_blocks(U);
     if (wb < 0) return -2;
-    std::vector<float> tw = host::make_twiddles(256);
+    std::vector<float> tw = host::make_twiddles(64 * C);
     std::vector<float> kt;
-    if (wb > 0) kt = host::make_ktab256(U, 16 * wb);
+    if (wb > 0) kt = host::make_ktab_big(64 * C, U, 16 * wb);
     const cf* twp = reinterpret_cast<const cf*>(tw.data());
     const float* ktp = kt.empty() ? nullptr : kt.data();
     const int64_t grid = g_grid > 0 && g_grid < nbatch ? g_grid : nbatch;
-    std::vector<float> ws((size_t)grid * (kWs128Bytes / sizeof(float)));
+    std::vector<float> ws((size_t)grid * (LdsBig<C>::kWsBytes / sizeof(float)));
     float* wsp = ws.data();
-    auto run = [&](auto fn) { rt::launch(grid, kThreads, fn, Lds128::total(16 * wb)); };
+    auto run = [&](auto fn) { rt::launch(grid, kThreads, fn, LdsBig<C>::total(16 * wb)); };
     switch (wb) {
-    case 0: run([&] { pair128_kernel<0>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
-    case 1: run([&] { pair128_kernel<1>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
-    case 2: run([&] { pair128_kernel<2>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
-    case 3: run([&] { pair128_kernel<3>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
-    default: run([&] { pair128_kernel<4>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    case 0: run([&] { pair128_kernel<C, 0>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    case 1: run([&] { pair128_kernel<C, 1>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    case 2: run([&] { pair128_kernel<C, 2>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    case 3: run([&] { pair128_kernel<C, 3>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    default: run([&] { pair128_kernel<C, 4>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
     }
     return 0;
+}
+
+extern "C" int emu_pair128(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
+                           int U, int cc_type, double* out, int* status) {
+    if (ny < 5 || nx < 5 || ny > 128 || nx > 128) return -1;
+    return emu_pair_big<4>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
+}
+
+extern "C" int emu_pair96(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
+                          int U, int cc_type, double* out, int* status) {
+    if (ny < 5 || nx < 5 || ny > 96 || nx > 96) return -1;
+    return emu_pair_big<3>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
 }
 
 extern "C" int emu_disp5_128(const float* ref, const float* im4, int64_t nbatch, int ny, int nx,

@@ -45,7 +45,8 @@ def pair(ref, img, upsample=1, cc=0):
     out = np.zeros((n, 2))
     st = np.zeros(n, np.int32)
     side = max(ref.shape[1:])
-    fn = lib().emu_pair128 if side > 64 else (lib().emu_pair32 if side <= 32 else lib().emu_pair)
+    fn = (lib().emu_pair32 if side <= 32 else lib().emu_pair if side <= 64 else
+          lib().emu_pair96 if side <= 96 else lib().emu_pair128)
     rc = fn(_p(ref, _fp), _p(img, _fp), ctypes.c_int64(n), ref.shape[1], ref.shape[2],
             int(upsample), int(cc), _p(out, _dp), _p(st, _ip))
     assert rc == 0, rc

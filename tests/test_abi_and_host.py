@@ -37,8 +37,12 @@ def test_argument_errors_without_gpu():
     assert lib.spx_workspace_bytes_displacement5(10, 64, 64, 1) == 10 * 4 * 64 * 64 * 4
     assert lib.spx_workspace_bytes_displacement5(10, 64, 64, 0) == 0
     assert lib.spx_workspace_bytes_xcorr(10, 64, 64) == 0
-    # 128 tile: 16 complex class planes of 64x64 + the 256 x (256+4) convolution, per workgroup
-    assert lib.spx_workspace_bytes_xcorr(10, 65, 64) == 10 * (16 * 2 * 64 * 64 + 256 * 260) * 4
+    # 96 tile: 9 complex class planes of 64x64 + the 192 x (192+4) convolution, per workgroup;
+    # 128 tile: 16 planes + 256 x (256+4)
+    assert lib.spx_workspace_bytes_xcorr(10, 65, 64) == 10 * (9 * 2 * 64 * 64 + 192 * 196) * 4
+    assert lib.spx_workspace_bytes_xcorr(10, 97, 64) == 10 * (16 * 2 * 64 * 64 + 256 * 260) * 4
+    # the reference mode keeps every cutout above 64 px on the 128 tile
+    assert lib.spx_workspace_bytes_displacement5(10, 65, 64, 0) == 10 * (16 * 2 * 64 * 64 + 256 * 260) * 4
     # argument validation happens before any HIP call
     assert lib.spx_xcorr_refine_f32(None, None, 1, 64, 64, 1, 0, None, None, None, 0, None) == -1
     assert lib.spx_xcorr_refine_f32(None, None, 0, 64, 64, 1, 0, None, None, None, 0, None) == 0

@@ -55,6 +55,23 @@ def test_pair_mode_vs_oracle_n128(spx, up, tol):
         assert np.max(np.abs(got - truth)) < 1e-3
 
 
+@pytest.mark.parametrize('up,tol', [(1, 1e-5), (2, 2e-5), (10, 2e-4), (20, 5e-4)])
+def test_pair_mode_vs_oracle_n96(spx, up, tol):
+    """96 tile (65..96 px, FFT period 192 = next_fast_len(2*96-1)): GPU vs oracle"""
+    ref, img, truth = datagen.pair_batch(11, 12, 96)
+    got, st = spx.xcorr_refine_batch(ref, img, upsample=up, return_status=True)
+    exp, est = orc.xcorr_refine_batch(ref, img, up)
+    assert np.array_equal(st, est)
+    assert np.max(np.abs(got - exp)) < tol
+    rng = np.random.default_rng(96)
+    for _ in range(6):                              # ragged shapes inside the tile
+        ny, nx = int(rng.integers(65, 97)), int(rng.integers(5, 97))
+        r, i = datagen.pair_set(ny, nx, rng.uniform(-2, 2), rng.uniform(-2, 2), min(ny, nx) / 10.0, 1.0, np.float32)
+        got = spx.xcorr_refine_batch(r[None], i[None], upsample=up, cc_type='NCC')
+        exp = orc.xcorr_refine(r, i, up, 'NCC')
+        assert np.max(np.abs(got[0] - np.array(exp))) < max(tol, 3e-5), (ny, nx)
+
+
 def test_pair_mode_u1_vs_reference_goldens(spx, golden_dir):
     g = _load(golden_dir, 'pair_u1.npz')
     for n in (32, 33, 64, 128):

@@ -47,6 +47,21 @@ def test_pair_mode_128_tile():
     assert np.max(np.abs(got[0] - np.array(e))) < 2e-5
 
 
+def test_pair_mode_96_tile():
+    """cutouts of 65..96 px: period-192 path (9 classes, radix-3 fold and combine)"""
+    ref, img, truth = datagen.pair_batch(6, 2, 96)
+    got, st = emu.pair(ref, img, 10)
+    exp, est = orc.xcorr_refine_batch(ref, img, 10)
+    assert np.max(np.abs(got - exp)) < 1e-4 and np.array_equal(st, est)
+    assert np.max(np.abs(got - truth)) < 2e-4
+    r, i = datagen.pair_set(65, 90, -1.3, 0.6, 6.0, 0.8, np.float32)
+    for up, name, code in ((1, 'CC', 0), (2, 'NCC', 1)):
+        got, st = emu.pair(r[None], i[None], up, code)
+        e = orc.xcorr_refine(r, i, up, name)
+        assert np.max(np.abs(got[0] - np.array(e))) < 2e-5
+    assert orc.tile_size(65, 90) == 96 and orc.tile_size(97, 5) == 128 and orc.tile_size(64, 64) == 64
+
+
 def test_pair_mode_32_tile():
     """cutouts up to 32 px: period-64 path, one wave per pair, 4 pairs per workgroup"""
     ref, img, truth = datagen.pair_batch(9, 6, 32)

@@ -19,6 +19,8 @@ cases = [(64, 6, 2, (1, 10) if quick else (1, 2, 10, 16, 20, 30, 43, 59)),
          (50, 2, 1, () if quick else (27,)),
          (32, 10, 1, (10,) if quick else (1, 10, 20, 43)),
          (21, 5, 1, () if quick else (59,)),
+         (96, 2, 1, (10,) if quick else (1, 2, 10, 27)),
+         (70, 1, 1, () if quick else (43,)),
          (128, 2, 1, (2,) if quick else (1, 11, 20, 43)),
          (97, 1, 1, () if quick else (59,))]
 for n, count, grid, ups in cases:
