@@ -61,21 +61,26 @@ SPX_DEVICE void stage_block128(unsigned char* lds, const float* __restrict__ ref
     float* zre = reinterpret_cast<float*>(lds + L::R_OFF);
     float* zim = zre + 64 * L::ZS;
     const bool aligned = ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(img)) & 15) == 0;
-    if (aligned && (nx & 3) == 0 && 64 * sy + 64 <= ny && 64 * sx + 64 <= nx) {
-        // block entirely inside the cutout: 16-byte loads, image rows read back to front
+    if (aligned && (nx & 3) == 0) {
+        // rows are 16-byte multiples: 16-byte loads (image rows read back to front), whole
+        // 4-pixel chunks are either inside the cutout or padding
         const int nx4 = nx >> 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + i * kThreads;
             const int yl = idx >> 4, x4 = idx & 15;
             const int y = yl + 64 * sy, xq = x4 + 16 * sx;
-            const f32x4 r = reinterpret_cast<const f32x4*>(ref)[(int64_t)y * nx4 + xq];
-            const f32x4 t = reinterpret_cast<const f32x4*>(img)[(int64_t)(ny - 1 - y) * nx4 + (nx4 - 1 - xq)];
+            const bool inside = y < ny && xq < nx4;
+            f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f}, t = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (inside) {
+                r = reinterpret_cast<const f32x4*>(ref)[(int64_t)y * nx4 + xq];
+                t = reinterpret_cast<const f32x4*>(img)[(int64_t)(ny - 1 - y) * nx4 + (nx4 - 1 - xq)];
+            }
             float rr[4] = {r[0], r[1], r[2], r[3]};
             float mm[4] = {t[3], t[2], t[1], t[0]};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (ns.active) {
+                if (ns.active && inside) {
                     if (mm[e] != 0.0f) { mm[e] = mm[e] - ns.im_mean; mm[e] = mm[e] / ns.im_std; }
                     rr[e] = rr[e] - ns.ref_mean;
                     rr[e] = rr[e] / ns.ref_std;
