@@ -90,7 +90,7 @@ const char* spx_last_error(void);
  * are processed entirely in registers/LDS; larger ones (the 96 tile, FFT period 192, for
  * 65..96 px and the 128 tile, period 256, above) keep per-workgroup class planes and the
  * full convolution in an L2-resident workspace of 435 / 772 KiB per resident workgroup
- * (independent of nbatch beyond the grid).  The reference mode uses the 128 tile above 64 px.
+ * (independent of nbatch beyond the grid).
  * For the reference mode `need_icc` adds room for the interlaced images when the
  * caller does not want them back (out_icc == NULL).
  */

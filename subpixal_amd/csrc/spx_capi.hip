@@ -267,7 +267,7 @@ size_t spx_workspace_bytes_xcorr(int64_t nbatch, int ny, int nx) {
     return (size_t)grid128(device_cus(), nbatch) * per_group;
 }
 
-// the reference mode runs every cutout above 64 px on the 128 tile
+// the phase-stamp diagnostic runs on the 128 tile whatever the shape
 static size_t workspace_bytes_tile128(int64_t nbatch, int ny, int nx) {
     if (nbatch <= 0 || (ny <= 64 && nx <= 64)) return 0;
     return (size_t)grid128(device_cus(), nbatch) * spx::kWs128Bytes;
@@ -275,7 +275,7 @@ static size_t workspace_bytes_tile128(int64_t nbatch, int ny, int nx) {
 
 size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int need_icc) {
     if (nbatch <= 0 || ny <= 0 || nx <= 0) return 0;
-    size_t b = workspace_bytes_tile128(nbatch, ny, nx);
+    size_t b = spx_workspace_bytes_xcorr(nbatch, ny, nx);
     if (need_icc) b += (size_t)nbatch * 4u * (size_t)ny * (size_t)nx * sizeof(float);
     return b;
 }
@@ -398,7 +398,7 @@ int spx_find_displacement5_f32(const float* ref, const float* im4, int64_t nbatc
     if (need > 0 && (!workspace || workspace_bytes < need))
         return fail(SPX_E_WORKSPACE, "workspace missing or smaller than spx_workspace_bytes_displacement5()");
     unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
-    const size_t tile_ws = workspace_bytes_tile128(nbatch, ny, nx);
+    const size_t tile_ws = spx_workspace_bytes_xcorr(nbatch, ny, nx);
     float* icc = out_icc ? out_icc : reinterpret_cast<float*>(wsb + tile_ws);
     DeviceTables* t = nullptr;
     int rc = current_tables(&t);
@@ -406,12 +406,13 @@ int spx_find_displacement5_f32(const float* ref, const float* im4, int64_t nbatc
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (ny > 64 || nx > 64) {
         const int lds = spx::Lds128::total(0);
-        auto kern = spx::disp5_128_kernel;
+        const bool t96 = ny <= 96 && nx <= 96;          // 96 tile (period 192), else 128 tile
+        auto kern = t96 ? spx::disp5_128_kernel<3> : spx::disp5_128_kernel<4>;
         rc = allow_lds(kern, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid128(t->num_cu, nbatch)), dim3(spx::kThreads), lds, s,
-                           ref, im4, nbatch, ny, nx, cc_type, t->tw256, icc, out_dxdy, out_status,
-                           reinterpret_cast<float*>(wsb));
+                           ref, im4, nbatch, ny, nx, cc_type, t96 ? t->tw192 : t->tw256, icc, out_dxdy,
+                           out_status, reinterpret_cast<float*>(wsb));
         SPX_HIP(hipGetLastError());
         return 0;
     }

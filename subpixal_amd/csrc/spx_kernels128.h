@@ -638,17 +638,18 @@ SPX_TKERNEL(256) void pair128_kernel(const float* __restrict__ ref, const float*
 }
 
 // ---------------------------------------------------------------------------
-// reference (5-image) mode, 128 tile
+// reference (5-image) mode, 96 / 128 tile
 // ---------------------------------------------------------------------------
+template <int C>
 SPX_TKERNEL(256) void disp5_128_kernel(const float* __restrict__ ref, const float* __restrict__ im4,
                                        int64_t nbatch, int ny, int nx, int cc_type,
                                        const cf* __restrict__ tw_g, float* __restrict__ icc_all,
                                        double* __restrict__ out_all, int* __restrict__ status,
                                        float* __restrict__ workspace) {
-    typedef Lds128 L;
+    typedef LdsBig<C> L;
     SPX_DYN_LDS(lds);
-    load_twiddles128<4>(lds, tw_g);
-    float* ws = workspace + (size_t)rt::block_id() * (kWs128Bytes / sizeof(float));
+    load_twiddles128<C>(lds, tw_g);
+    float* ws = workspace + (size_t)rt::block_id() * (L::kWsBytes / sizeof(float));
     const float* conv = ws + L::kConvOffsetFloats;
     unsigned char* scr = lds + L::SCR_OFF;
     const int64_t stride = (int64_t)ny * nx;
@@ -664,11 +665,11 @@ SPX_TKERNEL(256) void disp5_128_kernel(const float* __restrict__ ref, const floa
         PhaseClock<0> clk;
         for (int q = 0; q < 4; ++q) {
             const int ox = q & 1, oy = q >> 1;
-            conv_full128<4, 0>(lds, r, m4 + q * stride, ny, nx, ns, ws, clk);
+            conv_full128<C, 0>(lds, r, m4 + q * stride, ny, nx, ns, ws, clk);
             const int qx = tid & 127;
             if (qx < nx) {
                 for (int qy = tid >> 7; qy < ny; qy += kThreads / 128) {
-                    const float val = window_value128<4>(conv, ny, nx, qy, qx);
+                    const float val = window_value128<C>(conv, ny, nx, qy, qx);
                     const int gi = (2 * qy + oy) * NX + 2 * qx + ox;
                     icc[gi] = val;
                     if (better(val, gi, bv, bi)) { bv = val; bi = gi; }

@@ -118,13 +118,19 @@ extern "C" int emu_pair96(const float* ref, const float* img, int64_t nbatch, in
 extern "C" int emu_disp5_128(const float* ref, const float* im4, int64_t nbatch, int ny, int nx,
                              int cc_type, float* icc, double* out, int* status) {
     if (ny < 3 || nx < 3 || ny > 128 || nx > 128) return -1;
-    std::vector<float> tw = host::make_twiddles(256);
+    const bool t96 = ny <= 96 && nx <= 96;
+    std::vector<float> tw = host::make_twiddles(t96 ? 192 : 256);
     const cf* twp = reinterpret_cast<const cf*>(tw.data());
-    std::vector<float> ws((size_t)nbatch * (kWs128Bytes / sizeof(float)));
+    std::vector<float> ws((size_t)nbatch * ((t96 ? kWs96Bytes : kWs128Bytes) / sizeof(float)));
     float* wsp = ws.data();
-    rt::launch(nbatch, kThreads, [&] {
-        disp5_128_kernel(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, wsp);
-    }, Lds128::total(0));
+    if (t96)
+        rt::launch(nbatch, kThreads, [&] {
+            disp5_128_kernel<3>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, wsp);
+        }, LdsBig<3>::total(0));
+    else
+        rt::launch(nbatch, kThreads, [&] {
+            disp5_128_kernel<4>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, wsp);
+        }, LdsBig<4>::total(0));
     return 0;
 }
 

@@ -41,8 +41,7 @@ def test_argument_errors_without_gpu():
     # 128 tile: 16 planes + 256 x (256+4)
     assert lib.spx_workspace_bytes_xcorr(10, 65, 64) == 10 * (9 * 2 * 64 * 64 + 192 * 196) * 4
     assert lib.spx_workspace_bytes_xcorr(10, 97, 64) == 10 * (16 * 2 * 64 * 64 + 256 * 260) * 4
-    # the reference mode keeps every cutout above 64 px on the 128 tile
-    assert lib.spx_workspace_bytes_displacement5(10, 65, 64, 0) == 10 * (16 * 2 * 64 * 64 + 256 * 260) * 4
+    assert lib.spx_workspace_bytes_displacement5(10, 65, 64, 0) == 10 * (9 * 2 * 64 * 64 + 192 * 196) * 4
     # argument validation happens before any HIP call
     assert lib.spx_xcorr_refine_f32(None, None, 1, 64, 64, 1, 0, None, None, None, 0, None) == -1
     assert lib.spx_xcorr_refine_f32(None, None, 0, 64, 64, 1, 0, None, None, None, 0, None) == 0

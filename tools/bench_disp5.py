@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 import subpixal_amd, datagen
 N = int(os.environ.get('N', 20000))
-for n in (32, 64, 128):
+for n in (32, 64, 96, 128):
     ref, im4, truth = datagen.dither_batch(3, 64, n)
     reps = N // 64
     r = torch.from_numpy(ref).cuda().repeat(reps, 1, 1).contiguous()
