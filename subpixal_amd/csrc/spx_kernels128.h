@@ -60,55 +60,39 @@ SPX_DEVICE void stage_block128(unsigned char* lds, const float* __restrict__ ref
     const int tid = fresh_tid();
     float* zre = reinterpret_cast<float*>(lds + L::R_OFF);
     float* zim = zre + 64 * L::ZS;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(img)) & 15) == 0;
-    if (aligned && (nx & 3) == 0) {
-        // rows are 16-byte multiples: 16-byte loads (image rows read back to front), whole
-        // 4-pixel chunks are either inside the cutout or padding
-        const int nx4 = nx >> 2;
+    // 4-pixel chunks: one 16-byte load each (4-byte aligned is enough on gfx950) when the chunk
+    // lies inside its row, element loads for the chunk that straddles the row end, zeros in the
+    // padding; the image is read back to front (cc.py:114)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + i * kThreads;
-            const int yl = idx >> 4, x4 = idx & 15;
-            const int y = yl + 64 * sy, xq = x4 + 16 * sx;
-            const bool inside = y < ny && xq < nx4;
-            f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f}, t = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (inside) {
-                r = reinterpret_cast<const f32x4*>(ref)[(int64_t)y * nx4 + xq];
-                t = reinterpret_cast<const f32x4*>(img)[(int64_t)(ny - 1 - y) * nx4 + (nx4 - 1 - xq)];
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * kThreads;
+        const int yl = idx >> 4, x4 = idx & 15;
+        const int y = yl + 64 * sy, x = 4 * x4 + 64 * sx;
+        float rr[4] = {0.f, 0.f, 0.f, 0.f}, mm[4] = {0.f, 0.f, 0.f, 0.f};
+        if (y < ny && x < nx) {
+            const float* rrow = ref + (int64_t)y * nx + x;
+            const float* mrow = img + (int64_t)(ny - 1 - y) * nx + (nx - 1 - x);     // pixel x, then x+1 at -1, ...
+            if (x + 3 < nx) {
+                const F32x4U r = *reinterpret_cast<const F32x4U*>(rrow);
+                const F32x4U t = *reinterpret_cast<const F32x4U*>(mrow - 3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { rr[e] = r.v[e]; mm[e] = t.v[3 - e]; }
+            } else {
+                for (int e = 0; e < 4 && x + e < nx; ++e) { rr[e] = rrow[e]; mm[e] = mrow[-e]; }
             }
-            float rr[4] = {r[0], r[1], r[2], r[3]};
-            float mm[4] = {t[3], t[2], t[1], t[0]};
+            const int nin = nx - x < 4 ? nx - x : 4;          // pixels of the chunk inside the cutout
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (ns.active && inside) {
+                if (ns.active && e < nin) {
                     if (mm[e] != 0.0f) { mm[e] = mm[e] - ns.im_mean; mm[e] = mm[e] / ns.im_std; }
                     rr[e] = rr[e] - ns.ref_mean;
                     rr[e] = rr[e] / ns.ref_std;
                 }
                 mm[e] *= bal;
             }
-            *reinterpret_cast<f32x4*>(zre + yl * L::ZS + (x4 << 2)) = f32x4{rr[0], rr[1], rr[2], rr[3]};
-            *reinterpret_cast<f32x4*>(zim + yl * L::ZS + (x4 << 2)) = f32x4{mm[0], mm[1], mm[2], mm[3]};
         }
-        return;
-    }
-#pragma unroll 4
-    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
-        const int yl = idx >> 6, xl = idx & 63;
-        const int y = yl + 64 * sy, x = xl + 64 * sx;
-        float r = 0.0f, m = 0.0f;
-        if (y < ny && x < nx) {
-            r = ref[(int64_t)y * nx + x];
-            m = img[(int64_t)(ny - 1 - y) * nx + (nx - 1 - x)];     // flipped: cc.py:114
-            if (ns.active) {
-                if (m != 0.0f) { m = m - ns.im_mean; m = m / ns.im_std; }
-                r = r - ns.ref_mean;
-                r = r / ns.ref_std;
-            }
-            m *= bal;
-        }
-        zre[yl * L::ZS + xl] = r;
-        zim[yl * L::ZS + xl] = m;
+        *reinterpret_cast<f32x4*>(zre + yl * L::ZS + (x4 << 2)) = f32x4{rr[0], rr[1], rr[2], rr[3]};
+        *reinterpret_cast<f32x4*>(zim + yl * L::ZS + (x4 << 2)) = f32x4{mm[0], mm[1], mm[2], mm[3]};
     }
 }
 
@@ -151,27 +135,6 @@ SPX_DEVICE float balance128(unsigned char* scr, const float* __restrict__ ref,
         for (int i = tid; i < npx; i += kThreads) add(ref[i], img[i]);
     }
     return balance_factor(scr, ssq);
-}
-
-// C = 3: v += w_3^M (staged block), w_3 = exp(-2 pi i / 3): one complex multiply by a constant;
-// one specialised copy of the element loop per factor (the case split stays outside the loop)
-template <int C, int M>
-SPX_DEVICE void fold_block128(cf (&v)[8][8], const float* zre, const float* zim, int l1, int l0) {
-    typedef LdsBig<C> L;
-    static_assert(C == 3 && M >= 0 && M <= 3, "");
-#pragma unroll
-    for (int y1 = 0; y1 < 8; ++y1)
-#pragma unroll
-        for (int x1 = 0; x1 < 8; ++x1) {
-            const int a = (l1 + 8 * y1) * L::ZS + l0 + 8 * x1;
-            const cf t = cf{zre[a], zim[a]};
-            cf& d = v[y1][x1];
-            if constexpr (M == 0) d = d + t;
-            else {
-                const cf w = cf{-0.5f, M == 1 ? -0.86602540378443865f : 0.86602540378443865f};
-                d = d + cmul(t, w);
-            }
-        }
 }
 
 // One round: classes (cy, cx = wave) of the staged pair -> complex planes in the workspace.
@@ -222,11 +185,18 @@ SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref
                         else d = rt::add_pi(d, t);
                     }
             } else {
+                // one branch-free path: d += w t with w = 1, w_3 or w_3^2 (the products with
+                // w = 1 are exact), so the register tile never passes a control-flow join
                 const int m = (cy * sy + cx * sx) % C;
-                if (m == 0) fold_block128<C, 0>(v, zre, zim, l1, l0);
-                else if (m == 1) fold_block128<C, 1>(v, zre, zim, l1, l0);
-                else if (m == 2) fold_block128<C, 2>(v, zre, zim, l1, l0);
-                else fold_block128<C, 3>(v, zre, zim, l1, l0);
+                const cf w = cf{m == 0 ? 1.0f : -0.5f,
+                                m == 0 ? 0.0f : (m == 1 ? -0.86602540378443865f : 0.86602540378443865f)};
+#pragma unroll
+                for (int y1 = 0; y1 < 8; ++y1)
+#pragma unroll
+                    for (int x1 = 0; x1 < 8; ++x1) {
+                        const int a = (l1 + 8 * y1) * L::ZS + l0 + 8 * x1;
+                        rt::cmac_ip(v[y1][x1], cf{zre[a], zim[a]}, w);
+                    }
             }
         }
         rt::block_sync_lds();

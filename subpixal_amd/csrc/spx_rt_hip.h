@@ -116,6 +116,12 @@ SPX_DEVICE void cmulc_ip(f32x2& a, f32x2 w) {
         "v_pk_fma_f32 %0, %0, %2, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
         : "+v"(a), "=&v"(t) : "v"(w));
 }
+// d += t * w IN PLACE: two fused multiply-adds, no temporary
+SPX_DEVICE void cmac_ip(f32x2& d, f32x2 t, f32x2 w) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "+v"(d) : "v"(t), "v"(w));
+}
 // s + (-i) d = (s.x + d.y, s.y - d.x)
 SPX_DEVICE f32x2 add_mi(f32x2 s, f32x2 d) {
     f32x2 r;

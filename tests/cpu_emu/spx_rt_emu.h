@@ -80,6 +80,7 @@ SPX_DEVICE void atomic_max_i32(int* p, int v) { int o = __atomic_load_n(p, __ATO
 SPX_DEVICE void atomic_add_i32(int* p, int v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 SPX_DEVICE f32x2 cmul(f32x2 a, f32x2 w) { return f32x2{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
 SPX_DEVICE f32x2 cmulc(f32x2 a, f32x2 w) { return f32x2{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y}; }
+SPX_DEVICE void cmac_ip(f32x2& d, f32x2 t, f32x2 w) { const f32x2 p = cmul(t, w); d = f32x2{d.x + p.x, d.y + p.y}; }
 SPX_DEVICE void cmul_ip(f32x2& a, f32x2 w) { a = cmul(a, w); }
 SPX_DEVICE void cmulc_ip(f32x2& a, f32x2 w) { a = cmulc(a, w); }
 SPX_DEVICE f32x2 add_mi(f32x2 s, f32x2 d) { return f32x2{s.x + d.y, s.y - d.x}; }
