@@ -454,25 +454,44 @@ SPX_DEVICE void stage_pair(unsigned char* lds, const float* __restrict__ ref,
         ssq[1] = sm;
         return;
     }
-    for (int idx = tid; idx < 64 * 64; idx += kThreads) {
-        const int y = idx >> 6, x = idx & 63;
-        float r = 0.0f, m = 0.0f;
+    // every other shape: 4-pixel chunks, one 16-byte load each (4-byte aligned is enough on
+    // gfx950) when the chunk lies inside its row, element loads for the chunk that straddles
+    // the row end, zeros in the padding; the image is read back to front (cc.py:114)
+    struct __attribute__((packed, aligned(4))) U4 { float v[4]; };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * kThreads;
+        const int y = idx >> 4, x = (idx & 15) << 2;
+        float rr[4] = {0.f, 0.f, 0.f, 0.f}, mm[4] = {0.f, 0.f, 0.f, 0.f};
         if (y < ny && x < nx) {
-            r = ref[(int64_t)y * nx + x];
-            m = img[(int64_t)(ny - 1 - y) * nx + (nx - 1 - x)];     // flipped: cc.py:114
+            const float* rrow = ref + (int64_t)y * nx + x;
+            const float* mrow = img + (int64_t)(ny - 1 - y) * nx + (nx - 1 - x);
+            if (x + 3 < nx) {
+                const U4 r = *reinterpret_cast<const U4*>(rrow);
+                const U4 t = *reinterpret_cast<const U4*>(mrow - 3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { rr[e] = r.v[e]; mm[e] = t.v[3 - e]; }
+            } else {
+                for (int e = 0; e < 4 && x + e < nx; ++e) { rr[e] = rrow[e]; mm[e] = mrow[-e]; }
+            }
+            const int nin = nx - x < 4 ? nx - x : 4;          // pixels of the chunk inside the cutout
             if (ns.active) {
-                if (m != 0.0f) {           // cc.py:144-148: masked pixels only
-                    m = m - ns.im_mean;
-                    m = m / ns.im_std;
-                }
-                r = r - ns.ref_mean;       // cc.py:153-154: all pixels
-                r = r / ns.ref_std;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nin) {
+                        if (mm[e] != 0.0f) {           // cc.py:144-148: masked pixels only
+                            mm[e] = mm[e] - ns.im_mean;
+                            mm[e] = mm[e] / ns.im_std;
+                        }
+                        rr[e] = rr[e] - ns.ref_mean;   // cc.py:153-154: all pixels
+                        rr[e] = rr[e] / ns.ref_std;
+                    }
             }
         }
-        zre[y * L::ZS + x] = r;
-        zim[y * L::ZS + x] = m;
-        sr += r * r;
-        sm += m * m;
+        *reinterpret_cast<f32x4*>(zre + y * L::ZS + x) = f32x4{rr[0], rr[1], rr[2], rr[3]};
+        *reinterpret_cast<f32x4*>(zim + y * L::ZS + x) = f32x4{mm[0], mm[1], mm[2], mm[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sr += rr[e] * rr[e]; sm += mm[e] * mm[e]; }
     }
     ssq[0] = sr;
     ssq[1] = sm;
