@@ -6,7 +6,7 @@
 // fold_c(z)[x'] = z[x'] + w_C^c z[x'+64], w_C = exp(-2 pi i / C)  (per axis; the cutout spans at
 // most two 64-blocks), each again a 64x64 complex FFT done by one wave in registers with the
 // machinery of spx_kernels.h.  A workgroup (4 waves) runs C rounds of C classes (for C = 3 the
-// fourth wave only helps staging).  These tiles do not fit the LDS the way 64x64 does ("stresses
+// fourth wave helps staging and otherwise shadows class (cy, 0) without storing anything).  These tiles do not fit the LDS the way 64x64 does ("stresses
 // LDS tile sizing"), so the per-class results  g_c[l'] = sum_{k in c} Z[k]^2 e^{2 pi i k l'/P}
 // (complex, 64x64) go to a per-workgroup workspace that stays in L2/MALL, a radix-C pass combines
 // them into the full PxP real convolution  conv[l'+64s] = Im( sum_c conj(w_C)^(c.s) g_c[l'] ) / 2P^2
