@@ -224,7 +224,8 @@ def main():
                 'workload': 'BASELINE.json configs[%d]%s: %d %dx%d Gaussian-spot cutout pairs per GPU, '
                             'upsample=%d, inputs resident in HBM'
                             % (0 if tile <= 32 else 1 if tile <= 64 else 2,
-                               ' shape, on the GPU' if tile <= 32 else '', n_local, tile, tile, ups),
+                               ' shape, on the GPU' if tile <= 32 else (' family, 96 tile' if 64 < tile <= 96 else ''),
+                               n_local, tile, tile, ups),
                 'pairs_per_gpu': n_local, 'tile': tile, 'upsample': ups, 'cc_type': 'CC',
                 'parallelism': 'batch sharded over %d GPU(s); gather of (dx,dy) to rank 0' % world,
             },
