@@ -31,22 +31,42 @@ BYTES_PER_PAIR = 2 * TILE * TILE * 4 + 16 + 4
 
 
 # ---------------------------------------------------------------------------
-# CPU baseline ("port"): the oracle's restatement of the reference's own per-source
-# path cc.find_displacement (cc.py:21-95: 4 fftconvolve cross-correlations of 64x64
-# float32 cutouts + interlace + find_peak), timed on the host cores of this box.
+# CPU baseline ("port"): the oracle timed on the host cores of this box, three legs.
+#   pair_u10  -- THE SAME WORK as the GPU value: oracle.xcorr_refine(ref, img, upsample) on 64x64
+#                float32 pairs (zero-padded cross-power spectrum, coarse arg-max, matrix-DFT window,
+#                5x5 fit; float64 numpy -- the definition of the pair mode, not a tuned CPU code);
+#   pair_u1   -- the reference's own composition for ONE cross-correlation: fftconvolve 'same' +
+#                find_peak (cc.py:114 + cc.py:86), float32 FFT: an upper bound for any CPU code that
+#                goes through scipy for the same pair;
+#   reference -- cc.find_displacement restated (cc.py:21-95: 4 cross-correlations + interlace +
+#                find_peak per call, NCC), counted as 4 cross-correlations per call.
+# cpu_baseline.value is the same-work leg; the other two are reported beside it.
 # ---------------------------------------------------------------------------
 def _cpu_worker(args):
-    seed, count = args
+    seed, n_u10, n_u1, n_ref, tile, ups = args
     import numpy as np
     import datagen
     from oracle import subpixal_oracle as orc
-    ref, im4, _ = datagen.dither_batch(seed, 8, TILE)
-    orc.find_displacement(ref[0], *im4[0], cc_type='NCC')          # warm
+    ref, img, _ = datagen.pair_batch(seed, 8, tile)
+    r5, im4, _ = datagen.dither_batch(seed, 8, tile)
+    orc.xcorr_refine(ref[0], img[0], ups, full_grid=False)          # warm
+    orc.pair_shift_u1(ref[0], img[0])
+    orc.find_displacement(r5[0], *im4[0], cc_type='NCC')
+    out = []
     t0 = time.perf_counter()
-    for k in range(count):
+    for k in range(n_u10):
+        orc.xcorr_refine(ref[k % 8], img[k % 8], ups, full_grid=False)
+    out.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    for k in range(n_u1):
+        orc.pair_shift_u1(ref[k % 8], img[k % 8])
+    out.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    for k in range(n_ref):
         j = k % 8
-        orc.find_displacement(ref[j], im4[j, 0], im4[j, 1], im4[j, 2], im4[j, 3], cc_type='NCC')
-    return count, time.perf_counter() - t0
+        orc.find_displacement(r5[j], im4[j, 0], im4[j, 1], im4[j, 2], im4[j, 3], cc_type='NCC')
+    out.append(time.perf_counter() - t0)
+    return out
 
 
 def kernel_name(tile, upsample):
@@ -54,10 +74,10 @@ def kernel_name(tile, upsample):
     WB = 0 for upsample 1, else ceil((upsample + 5) / 16)."""
     wb = 0 if upsample == 1 else (upsample + 5 + 15) // 16
     if tile <= 32:
-        return 'spx::pair32_kernel<%d>' % wb
-    if tile <= 64:
-        return 'spx::pair_kernel<2,%d>' % wb
-    return 'spx::pair128_kernel<%d,%d>' % (3 if tile <= 96 else 4, wb)
+        return 'spx::pair32_kernel<%d, float>' % wb
+    if tile <= 85:
+        return 'spx::pair_kernel<2, %d, 0, %s, float>' % (wb, 'true' if tile > 64 else 'false')
+    return 'spx::pair128_kernel<3, %d, 0, float>' % wb
 
 
 def usable_cores():
@@ -77,26 +97,65 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(per_core=2500):
+def cpu_baseline(tile=TILE, upsample=UPSAMPLE, n_u10=1200, n_u1=3000, n_ref=2000):
     import multiprocessing as mp
     cores = usable_cores()
+    if tile > 64:                      # larger cutouts cost ~4x per pair: keep the leg bounded
+        n_u10, n_u1, n_ref = n_u10 // 4, n_u1 // 4, n_ref // 4
     ctx = mp.get_context('fork')
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(100 + i, per_core) for i in range(cores)])
+        res = pool.map(_cpu_worker, [(100 + i, n_u10, n_u1, n_ref, tile, upsample) for i in range(cores)])
     wall = time.perf_counter() - t0
-    busy = max(r[1] for r in res)
-    total = sum(r[0] for r in res)
+    slow = [max(r[k] for r in res) for k in range(3)]     # slowest process per leg
     return {
-        'value': 4.0 * total / busy,
+        'value': cores * n_u10 / slow[0],
         'unit': 'cross-correlations/s',
         'cores': cores,
         'kind': 'port',
-        'sample': ('oracle.find_displacement (reference cc.py:21-95 restated: 4 cross-correlations '
-                   '+ 2x interlace + find_peak per call, NCC, 64x64 float32) x %d calls on each of '
-                   '%d processes; rate = 4*calls / slowest process time (%.1f s, wall %.1f s)'
-                   % (per_core, cores, busy, wall)),
+        'sample': ('same work as the GPU value: oracle.xcorr_refine (pair mode, upsample=%d, %dx%d float32 '
+                   'pairs, float64 numpy) x %d pairs on each of %d processes; rate = pairs / slowest '
+                   'process time (%.1f s); whole CPU leg %.1f s wall' % (upsample, tile, tile, n_u10, cores,
+                                                                        slow[0], wall)),
+        'pair_u1': {'value': cores * n_u1 / slow[1], 'unit': 'cross-correlations/s',
+                    'sample': "reference's own composition for one pair (fftconvolve 'same' + find_peak, "
+                              "cc.py:114+86, float32 FFT) x %d per process" % n_u1},
+        'reference_mode': {'value': 4.0 * cores * n_ref / slow[2], 'unit': 'cross-correlations/s',
+                           'sample': 'oracle.find_displacement (cc.py:21-95 restated, NCC): 4 cross-correlations '
+                                     '+ interlace + find_peak per call x %d calls per process' % n_ref},
     }
+
+
+# ---------------------------------------------------------------------------
+# Compute roofline (SURVEY 8d "record roofline.compute_fraction alongside the HBM fraction"):
+# floating-point operations one pair EXECUTES, from the ISA of the kernel instance
+# (tools/kernel_flops.py: packed/scalar f32 VALU + f64 fit + v_mfma_f32_16x16x4_f32; DESIGN.md
+# section 5 has the derivation), against the 157.3 TFLOP/s f32 vector (= f32 MFMA) peak of
+# MI355X_MICROARCH.md.  Straight-line kernels only (32/64 tile): the period-192 kernel loops over
+# its 9 classes, for it the count is the analytic one of DESIGN.md.
+# ---------------------------------------------------------------------------
+F32_PEAK_TFLOPS = 157.3
+FLOPS_PER_PAIR = {          # (kernel family, refinement-window blocks) -> (vector, matrix) MFLOP
+    ('64', 1): (2.086, 0.655),
+    ('64fold', 1): (2.157, 0.655),
+    ('192', 2): (5.9, 2.75),
+}
+
+
+def flops_per_pair(tile, upsample):
+    wb = 0 if upsample == 1 else (upsample + 5 + 15) // 16
+    fam = '32' if tile <= 32 else '64' if tile <= 64 else '64fold' if tile <= 85 else '192'
+    return FLOPS_PER_PAIR.get((fam, wb))
+
+
+def kernel_commit():
+    """Commit the kernel sources were last changed in (ties a PMC traffic file to a build)."""
+    import subprocess
+    try:
+        return subprocess.check_output(['git', '-C', ROOT, 'log', '-1', '--format=%h', '--',
+                                        'subpixal_amd/csrc'], text=True, stderr=subprocess.DEVNULL).strip()
+    except (OSError, subprocess.CalledProcessError):
+        return None
 
 
 def main():
@@ -104,7 +163,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--pairs', type=int, default=PAIRS_PER_GPU)
+    ap.add_argument('--pairs', type=int, default=None,
+                    help='pairs per GPU (default 1e5 = configs[1]; at 8 GPUs 1.25e6 = configs[3], 1e7 pairs in all)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--tile', type=int, default=TILE, help='cutout side (64 = config 2, 128 = config 3)')
     ap.add_argument('--upsample', type=int, default=UPSAMPLE)
@@ -123,7 +183,7 @@ def main():
     # CPU baseline first (fork pool), before this process touches the GPU
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(args.tile, args.upsample)
 
     import torch
     import torch.distributed as dist
@@ -147,7 +207,9 @@ def main():
             return d
         return spx_dist.gather_shifts(d.cpu() if on_cpu else d, n_total=n_total, dst=0)
 
-    n_local = args.pairs
+    # BASELINE.json configs[3]: 1e7 64x64 pairs over 8 GPUs = 1.25e6 pairs (41 GB) per GPU
+    config4 = args.pairs is None and world == 8 and args.tile == TILE
+    n_local = args.pairs if args.pairs is not None else (1250000 if config4 else PAIRS_PER_GPU)
     n_total = n_local * world
     # inputs generated on the device, resident in HBM before the timed region
     tile, ups = args.tile, args.upsample
@@ -198,13 +260,20 @@ def main():
     if rank == 0:
         # HBM traffic of the same launch from the committed PMC passes (rocprofv3 cannot run
         # inside this process); only quoted for the configuration it was measured on
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')))
-            if pmc.get('pairs_per_launch') == n_local and tile == TILE and ups == UPSAMPLE:
-                traffic = pmc['hbm_bytes_per_launch']
-        except (OSError, ValueError, KeyError):
-            pass
+        # ... and only when that file was measured on THIS build of the kernels
+        traffic, traffic_src = None, None
+        for rnd in ('r02', 'r01'):
+            try:
+                name = 'pmc_traffic.json' if (tile == TILE and ups == UPSAMPLE) else \
+                    'pmc_traffic_%d_u%d.json' % (tile, ups)
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', rnd, name)))
+                if pmc.get('pairs_per_launch') == n_local and pmc.get('tile', TILE) == tile and \
+                        pmc.get('upsample', UPSAMPLE) == ups and pmc.get('kernel_commit') == kernel_commit():
+                    traffic = pmc['hbm_bytes_per_launch']
+                    traffic_src = 'profiles/%s/%s' % (rnd, name)
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
         value = n_total * args.steps / elapsed
         achieved = n_local * bytes_per_pair / (kern_ms * 1e-3) / 1e9
         out = {
@@ -223,8 +292,9 @@ def main():
             'config': {
                 'workload': 'BASELINE.json configs[%d]%s: %d %dx%d Gaussian-spot cutout pairs per GPU, '
                             'upsample=%d, inputs resident in HBM'
-                            % (0 if tile <= 32 else 1 if tile <= 64 else 2,
-                               ' shape, on the GPU' if tile <= 32 else (' family, 96 tile' if 64 < tile <= 96 else ''),
+                            % (3 if config4 else 0 if tile <= 32 else 1 if tile <= 64 else 2,
+                               ' (1e7 pairs over 8 GPUs)' if config4 else
+                               ' shape, on the GPU' if tile <= 32 else ('' if tile in (64, 128) else ' family'),
                                n_local, tile, tile, ups),
                 'pairs_per_gpu': n_local, 'tile': tile, 'upsample': ups, 'cc_type': 'CC',
                 'parallelism': 'batch sharded over %d GPU(s); gather of (dx,dy) to rank 0' % world,
@@ -236,15 +306,29 @@ def main():
                 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
                 'traffic': traffic,
-                'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01/pmc_traffic.json)',
+                'traffic_unit': 'HBM bytes per launch from the PMC passes of the same command on this kernel '
+                                'build (%s); null = not measured for this build/config' % traffic_src,
                 'algorithmic_bytes_per_launch': n_local * bytes_per_pair,
                 'kernel': kernel_name(tile, args.upsample),
                 'kernel_ms': kern_ms,
                 'bytes_per_pair': bytes_per_pair,
                 'pairs_per_launch': n_local,
             },
-            'max_abs_err_px_vs_truth': err,
         }
+        fl = flops_per_pair(tile, ups)
+        if fl is not None:
+            tf = sum(fl) * 1e6 * n_local / (kern_ms * 1e-3) / 1e12
+            out['roofline'].update({
+                'compute_fraction': tf / F32_PEAK_TFLOPS,
+                'compute_achieved_tflops': tf,
+                'compute_peak_tflops': F32_PEAK_TFLOPS,
+                'flops_per_pair': sum(fl) * 1e6,
+                'flops_split': 'vector %.3f + v_mfma_f32_16x16x4_f32 %.3f MFLOP per pair '
+                               '(ISA census, tools/kernel_flops.py; DESIGN.md section 5)' % fl,
+            })
+        out.update({
+            'max_abs_err_px_vs_truth': err,
+        })
         if cpu is not None:
             out['cpu_baseline'] = cpu
         print(json.dumps(out))

@@ -39,8 +39,14 @@
  *     the early returns of centroid.py:171-172, 218-225, 230-236.
  *   - Constant tables (twiddles, interpolation kernels) are built on first use
  *     per device and upsampling factor; call spx_prepare() up front if the launch
- *     must not allocate (stream capture).
- *   - One host thread per device at a time.
+ *     must not allocate (stream capture).  spx_shutdown() frees them.
+ *   - Host threads may share a device: enqueues on one device are serialised by the library
+ *     (a per-device mutex held only while a launch is issued).
+ *   - Input element types: the _f32 entries take float32 pixels (the type BASELINE.json
+ *     measures); the _f64 entries take float64 pixels and form the `!= 0` masks, the pooled
+ *     statistics and the normalised pixels of cc.py:131-156 in float64 -- the dtype the
+ *     reference computes in for float64 cutouts -- before rounding to float32 for the
+ *     transforms.  All arithmetic after staging is float32 (fit: float64) in both.
  */
 #ifndef SUBPIXAL_HIP_H
 #define SUBPIXAL_HIP_H
@@ -52,7 +58,7 @@
 extern "C" {
 #endif
 
-#define SPX_ABI_VERSION 1
+#define SPX_ABI_VERSION 2
 
 /* cc_type (cc.py:107-111; anything else than NCC/ZNCC means plain CC) */
 #define SPX_CC 0
@@ -66,6 +72,8 @@ extern "C" {
 #define SPX_ST_OUTSIDE 3   /* vertex outside image -> integer peak  (centroid.py:230)    */
 #define SPX_ST_WINDOW 4    /* fine peak not bracketed by the refinement window           */
 #define SPX_ST_FEWPTS 5    /* find_peak: fewer than 6 usable points (centroid.py:160,186,202) */
+#define SPX_ST_NONFINITE 6 /* a NaN/Inf pixel made the correlation NaN: integer position (0, 0),
+                              which is what numpy.argmax + centroid.py:171 return for it        */
 
 /* error codes */
 #define SPX_E_ARG (-1)        /* bad argument                              */
@@ -81,16 +89,22 @@ int spx_abi_version(void);
 int spx_device_count(void);
 /* select `device` for this process/thread and build its constant tables */
 int spx_init(int device);
-/* build the tables for `upsample` now (so later launches do not allocate) */
+/* Build, for the current device, the interpolation tables of `upsample` for EVERY kernel family
+ * (cutouts up to 32 / 85 / 128 px) and raise the dynamic-LDS limit of every kernel instance a
+ * later spx_xcorr_refine_* (with this upsample) or spx_find_displacement5_* call can dispatch to,
+ * whatever its cutout shape and input type: after it such calls neither allocate nor touch
+ * function attributes, so they may be issued inside a stream capture. */
 int spx_prepare(int upsample);
+/* Free the device tables of every device this process initialised (after synchronising them);
+ * the next call builds them again.  No call may be in flight on another host thread. */
+int spx_shutdown(void);
 const char* spx_last_error(void);
 
 /*
- * Bytes of device scratch the batched calls need (0 when none).  Cutouts up to 64x64
- * are processed entirely in registers/LDS; larger ones (the 96 tile, FFT period 192, for
- * 65..96 px and the 128 tile, period 256, above) keep per-workgroup class planes and the
- * full convolution in an L2-resident workspace of 435 / 772 KiB per resident workgroup
- * (independent of nbatch beyond the grid).
+ * Bytes of device scratch the batched calls need (0 when none).  Cutouts up to 85 px per side
+ * are processed entirely in registers/LDS (FFT period 64 up to 32 px, 128 up to 85 px); larger
+ * ones (period 192, up to 128 px) keep per-workgroup class planes and the full convolution in a
+ * workspace of 435 KiB per resident workgroup (independent of nbatch beyond the grid).
  * For the reference mode `need_icc` adds room for the interlaced images when the
  * caller does not want them back (out_icc == NULL).
  */
@@ -98,9 +112,11 @@ size_t spx_workspace_bytes_xcorr(int64_t nbatch, int ny, int nx);
 size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int need_icc);
 
 /*
- * Pair mode.  ref, img: float32 [nbatch][ny][nx].  For every pair: linear
- * cross-correlation on the zero-padded grid (FFT period 64 / 128 / 192 / 256 for cutouts up
- * to 32 / 64 / 96 / 128 px per side: scipy's next_fast_len(2n-1)), arg-max over the flipped
+ * Pair mode.  ref, img: float32 (or float64) [nbatch][ny][nx].  For every pair: linear
+ * cross-correlation on the zero-padded grid (FFT period 64 / 128 / 192 for cutouts up to
+ * 32 / 85 / 128 px per side: scipy's next_fast_len(2n-1) for n = 32 and 64, above that the
+ * smallest multiple of 64 that leaves the 'same' window free of circular aliasing, i.e. the
+ * same numbers at every integer lag), arg-max over the flipped
  * 'same' window, U-times trigonometric upsampling around it, 5x5 quadratic fit
  * (find_peak(., 5, 'all')), shift = peak/U - (n-1)//2.
  *   out_dxdy   : float64 [nbatch][2]  (dx, dy)
@@ -108,6 +124,9 @@ size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int nee
  * 5 <= ny, nx <= SPX_MAX_SIDE; 1 <= upsample <= SPX_MAX_UPSAMPLE.
  */
 int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
+                         int upsample, int cc_type, double* out_dxdy, int32_t* out_status,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int spx_xcorr_refine_f64(const double* ref, const double* img, int64_t nbatch, int ny, int nx,
                          int upsample, int cc_type, double* out_dxdy, int32_t* out_status,
                          void* workspace, size_t workspace_bytes, void* stream);
 
@@ -121,6 +140,10 @@ int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int
  * 3 <= ny, nx <= SPX_MAX_SIDE.
  */
 int spx_find_displacement5_f32(const float* ref, const float* im4, int64_t nbatch, int ny,
+                               int nx, int cc_type, double* out_dxdy, int32_t* out_status,
+                               float* out_icc, void* workspace, size_t workspace_bytes,
+                               void* stream);
+int spx_find_displacement5_f64(const double* ref, const double* im4, int64_t nbatch, int ny,
                                int nx, int cc_type, double* out_dxdy, int32_t* out_status,
                                float* out_icc, void* workspace, size_t workspace_bytes,
                                void* stream);

@@ -35,11 +35,11 @@ from scipy import signal
 
 __all__ = [
     'py2round', 'find_peak', 'find_peak_5x5_all', 'normalize', 'xcorr_same',
-    'xcorr_same_direct', 'build_icc', 'find_displacement', 'tile_size',
+    'xcorr_same_direct', 'build_icc', 'find_displacement', 'tile_size', 'fft_period',
     'cross_power_spectrum', 'upsampled_cc', 'upsampled_cc_window',
     'xcorr_refine', 'xcorr_refine_batch', 'find_displacement_batch',
     'QUAD_PINV_5X5', 'STATUS_OK', 'STATUS_EDGE', 'STATUS_NOMAX',
-    'STATUS_OUTSIDE', 'primary_boxes', 'blot_affine4',
+    'STATUS_OUTSIDE', 'STATUS_NONFINITE', 'primary_boxes', 'blot_affine4',
 ]
 
 # per-item status codes shared with the HIP library (include/subpixal_hip.h)
@@ -47,6 +47,8 @@ STATUS_OK = 0        # quadratic vertex accepted
 STATUS_EDGE = 1      # arg-max in row/column 0: integer peak (centroid.py:171-172)
 STATUS_NOMAX = 2     # fitted quadric has no maximum: box centre (centroid.py:218-225)
 STATUS_OUTSIDE = 3   # vertex outside the image: integer peak (centroid.py:230-236)
+STATUS_NONFINITE = 6  # NaN/Inf input: the whole correlation is NaN, numpy.argmax returns 0 and
+#                       find_peak the integer position (0, 0) (centroid.py:114, 171-172)
 
 
 # --------------------------------------------------------------------------
@@ -345,6 +347,8 @@ def find_displacement(ref_image, image00, image10, image01, image11,
                          cc_type)
     xm, ym = find_peak(icc, peak_fit_box=5, peak_search_box='all',
                        _status=_status)
+    if _status is not None and not np.all(np.isfinite(icc)):
+        _status[-1] = STATUS_NONFINITE
     xc = (icc.shape[1] - 1) // 4
     yc = (icc.shape[0] - 1) // 4
     dx = 0.5 * xm - xc
@@ -369,18 +373,37 @@ def find_displacement_batch(ref, im4, cc_type='NCC'):
 # --------------------------------------------------------------------------
 # Pair / upsample=U mode (not in the reference)
 # --------------------------------------------------------------------------
-def tile_size(ny, nx):
-    """Smallest tile T >= max(ny, nx) among the ones the HIP library implements: 32, 64,
-    96, 128.  The pair mode's FFT period is P = 2T (= scipy's next_fast_len(2n-1) for
-    n = 32, 64, 96, 128)."""
+def fft_period(ny, nx):
+    """FFT period P of the pair mode's trigonometric interpolant (and of the HIP library's
+    transforms) for an (ny, nx) cutout, n = max(ny, nx):
+
+    * n <= 32: 64, n <= 64: 128 -- scipy's ``next_fast_len(2n-1)`` for n = 32, 64 (cc.py:114);
+    * above: the smallest multiple of 64 for which the reference's 'same' window (the only lags
+      cc.py:114-126 keeps) is free of circular aliasing: lag index ``l`` of the full linear
+      correlation runs over ``[0, 2n-2]`` and the window over ``[(n-1)//2, (n-1)//2 + n - 1]``,
+      so ``P > 2n - 2 - (n-1)//2`` suffices: 128 up to n = 85, 192 up to n = 128, 256 up to 170 ...
+
+    At integer lags (upsample = 1, and the reference's 5-image mode) any alias-free period gives
+    the SAME numbers as scipy's own choice; the period only enters the definition of the
+    interpolant between the integer lags."""
     n = max(ny, nx)
-    for t in (32, 64, 96):
+    if n <= 32:
+        return 64
+    if n <= 85:
+        return 128
+    need = 2 * n - 2 - (n - 1) // 2 + 1
+    return 64 * ((need + 63) // 64)
+
+
+def tile_size(ny, nx):
+    """Name of the kernel family of the HIP library that takes an (ny, nx) cutout: 32, 64,
+    85 (the 64 tile's fold path, period 128) or 128 (period 192); larger cutouts use the
+    general path with the period of :func:`fft_period`."""
+    n = max(ny, nx)
+    for t in (32, 64, 85, 128):
         if n <= t:
             return t
-    t = 128
-    while t < n:
-        t *= 2
-    return t
+    return n
 
 
 def cross_power_spectrum(ref, img, period):
@@ -407,14 +430,14 @@ def _pad_spectrum_1d(spec, period, up, axis):
 
 def upsampled_cc(ref, img, upsample):
     """The pair-mode fine cross-correlation image ``F[qy, qx]`` of shape
-    ``(U*ny, U*nx)``: the real trigonometric interpolant (period P = 2T in both
+    ``(U*ny, U*nx)``: the real trigonometric interpolant (period P = fft_period(ny, nx) in both
     axes, Nyquist bin split symmetrically) of the zero-padded linear
     cross-correlation, sampled at lag ``(n - 1 - n//2) - q/U`` -- i.e. the
     reference's flipped 'same' window (cc.py:114-126) on a U-times finer grid.
     U=1 gives ``xcorr_same(ref, img)[::-1, ::-1]`` (up to rounding)."""
     ny, nx = ref.shape
     up = int(upsample)
-    period = 2 * tile_size(ny, nx)
+    period = fft_period(ny, nx)
     spec = cross_power_spectrum(ref, img, period)
     if up > 1:
         spec = _pad_spectrum_1d(spec, period, up, 0)
@@ -431,7 +454,7 @@ def upsampled_cc_window(ref, img, upsample, qy, qx):
     the cross-power spectrum (no (U*P)^2 grid); used for large n*U."""
     ny, nx = ref.shape
     up = int(upsample)
-    period = 2 * tile_size(ny, nx)
+    period = fft_period(ny, nx)
     spec = cross_power_spectrum(ref, img, period)
     k = np.fft.fftfreq(period, 1.0 / period)          # signed, -P/2 at index P/2
     wgt = np.ones(period)
@@ -463,8 +486,13 @@ def xcorr_refine(ref, img, upsample=1, cc_type='CC', _status=None,
     if cc_type in ('NCC', 'ZNCC'):
         ref, (img,) = normalize(ref, [img], cc_type == 'ZNCC')
     if full_grid is None:
-        full_grid = (2 * tile_size(ny, nx) * up) <= 2048
+        full_grid = (fft_period(ny, nx) * up) <= 2048
     st = []
+    if not (np.all(np.isfinite(ref)) and np.all(np.isfinite(img))):
+        # every lag of an FFT correlation is NaN then: numpy.argmax -> index 0 -> edge rule
+        if _status is not None:
+            _status.append(STATUS_NONFINITE)
+        return 0.0 - (nx - 1) // 2, 0.0 - (ny - 1) // 2
     if full_grid:
         fine = upsampled_cc(ref, img, up)
         xm, ym = find_peak(fine, peak_fit_box=5, peak_search_box='all',

@@ -9,13 +9,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libsubpixal_hip.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_SIDE = 128
 MAX_UPSAMPLE = 59
 
 CC_CODES = {'CC': 0, 'NCC': 1, 'ZNCC': 2}
 
-ST_OK, ST_EDGE, ST_NOMAX, ST_OUTSIDE, ST_WINDOW, ST_FEWPTS = range(6)
+ST_OK, ST_EDGE, ST_NOMAX, ST_OUTSIDE, ST_WINDOW, ST_FEWPTS, ST_NONFINITE = range(7)
 
 _c = ctypes
 _vp = _c.c_void_p
@@ -24,12 +24,17 @@ _SIGNATURES = {
     'spx_device_count': (_c.c_int, []),
     'spx_init': (_c.c_int, [_c.c_int]),
     'spx_prepare': (_c.c_int, [_c.c_int]),
+    'spx_shutdown': (_c.c_int, []),
     'spx_last_error': (_c.c_char_p, []),
     'spx_workspace_bytes_xcorr': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int]),
     'spx_workspace_bytes_displacement5': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int]),
     'spx_xcorr_refine_f32': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                         _c.c_int, _vp, _vp, _vp, _c.c_size_t, _vp]),
+    'spx_xcorr_refine_f64': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
+                                        _c.c_int, _vp, _vp, _vp, _c.c_size_t, _vp]),
     'spx_find_displacement5_f32': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int,
+                                              _c.c_int, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
+    'spx_find_displacement5_f64': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int,
                                               _c.c_int, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     'spx_find_peak_f64': (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                      _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _vp]),

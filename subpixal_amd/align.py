@@ -20,9 +20,26 @@ iterative sigma clipping).  It is a few-thousand-point 2x3 least squares and sta
 """
 import numpy as np
 
-from . import cc
+from . import _ffi, cc
 
-__all__ = ['find_linear_fit', 'iter_linear_fit', 'measure_shifts', 'measure_shifts_affine']
+__all__ = ['find_linear_fit', 'iter_linear_fit', 'measure_shifts', 'measure_shifts_affine',
+           'usable_status', 'ST_SKIPPED']
+
+# per-source status of the measurement: the library's SPX_ST_* codes (include/subpixal_hip.h) or
+ST_SKIPPED = -1          # cutout shape outside what the kernels take (3..128 px per side): not measured
+
+
+def usable_status(status):
+    """True where a displacement is one the reference itself would have produced from finite data:
+    accepted vertex (0) or one of ``find_peak``'s own fallbacks (edge 1, no maximum 2, vertex outside 3:
+    centroid.py:171-172, 218-236).  Non-finite cutouts (6), an unbracketed refinement window (4) and
+    skipped shapes (-1) carry no measurement; ``find_linear_fit`` gives them zero weight."""
+    status = np.asarray(status)
+    return (status >= _ffi.ST_OK) & (status <= _ffi.ST_OUTSIDE)
+
+
+def _shape_ok(shape):
+    return len(shape) == 2 and all(3 <= n <= _ffi.MAX_SIDE for n in shape)
 
 
 # ----------------------------------------------------------------------------
@@ -76,7 +93,9 @@ def iter_linear_fit(xy, uv, wxy=None, wuv=None, fitgeom='general', center=None, 
         if extra is not None:
             w = w * np.asarray(extra, dtype=np.float64)
     c = np.zeros(2) if center is None else np.asarray(center, dtype=np.float64)
-    mask = np.ones(n, dtype=bool)
+    mask = w > 0.0 if np.any(w == 0.0) else np.ones(n, dtype=bool)     # zero weight = not a measurement
+    if mask.sum() < minpts:
+        raise ValueError("Not enough points with non-zero weight for the requested fit geometry.")
     eff = 0
     for it in range(max(0, int(nclip)) + 1):
         f, t = _weighted_fit(xy[mask] - c, uv[mask] - c, w[mask], fitgeom)
@@ -109,30 +128,43 @@ def iter_linear_fit(xy, uv, wxy=None, wuv=None, fitgeom='general', center=None, 
 # ----------------------------------------------------------------------------
 # the batched loop body of align.py:656-699
 # ----------------------------------------------------------------------------
-def measure_shifts(ref_tiles, im4_tiles, cc_type='NCC', full_output=False):
+def measure_shifts(ref_tiles, im4_tiles, cc_type='NCC', full_output=False, return_status=False):
     """Displacements for lists of same-or-mixed-shape cutouts: ``ref_tiles[k]`` is a 2-D
     array, ``im4_tiles[k]`` its four dithered blots (00, 10, 01, 11).  One launch per
-    distinct shape.  Returns ``dxdy [N, 2]`` (and the list of interlaced images)."""
+    distinct shape.  Returns ``dxdy [N, 2]`` (then the list of interlaced images with
+    ``full_output``, then ``status [N]`` with ``return_status``).  A cutout whose shape the kernels
+    do not take (outside 3..128 px per side) is not measured: shift 0, status ST_SKIPPED --
+    one oversized source must not abort the whole fit."""
     n = len(ref_tiles)
-    dxdy = np.empty((n, 2), dtype=np.float64)
+    dxdy = np.zeros((n, 2), dtype=np.float64)
+    status = np.full(n, ST_SKIPPED, dtype=np.int32)
     iccs = [None] * n
     groups = {}
     for k, r in enumerate(ref_tiles):
         shapes = {np.shape(r)} | {np.shape(b) for b in im4_tiles[k]}
         if len(shapes) != 1:
             raise ValueError("All cutouts must have same shape.")       # cc.py:103-105
-        groups.setdefault(np.shape(r), []).append(k)
+        if _shape_ok(np.shape(r)):
+            groups.setdefault(np.shape(r), []).append(k)
     for shape, idx in groups.items():
-        ref = np.stack([np.asarray(ref_tiles[k], dtype=np.float32) for k in idx])
-        im4 = np.stack([np.stack([np.asarray(b, dtype=np.float32) for b in im4_tiles[k]])
+        f64 = all(np.asarray(ref_tiles[k]).dtype == np.float64 for k in idx)
+        dt = np.float64 if f64 else np.float32
+        ref = np.stack([np.asarray(ref_tiles[k], dtype=dt) for k in idx])
+        im4 = np.stack([np.stack([np.asarray(b, dtype=dt) for b in im4_tiles[k]])
                         for k in idx])
-        res = cc.find_displacement_batch(ref, im4, cc_type=cc_type, full_output=full_output)
-        d, icc = (res if full_output else (res, None))
-        dxdy[idx] = d
+        res = cc.find_displacement_batch(ref, im4, cc_type=cc_type, full_output=full_output,
+                                         return_status=True)
+        dxdy[idx] = res[0]
+        status[idx] = res[-1]
         if full_output:
             for j, k in enumerate(idx):
-                iccs[k] = icc[j]
-    return (dxdy, iccs) if full_output else dxdy
+                iccs[k] = res[1][j]
+    out = [dxdy]
+    if full_output:
+        out.append(iccs)
+    if return_status:
+        out.append(status)
+    return out[0] if len(out) == 1 else tuple(out)
 
 
 def _image_xy(ct, x, y, wcslin):
@@ -148,28 +180,33 @@ def measure_shifts_affine(img_tiles, drz_tiles, affine, gain=None, cc_type='NCC'
     """The loop body of align.py:656-689 with the four blots made on the GPU
     (``blot.blot_affine4_batch``): ``img_tiles[k]`` and ``drz_tiles[k]`` are 2-D arrays,
     ``affine[k]`` maps image-cutout pixels to drizzled-cutout pixels.  The blots never leave
-    the device.  Returns ``(dxdy [N, 2], interlaced images, non-shifted blots)``."""
+    the device.  Returns ``(dxdy [N, 2], interlaced images, non-shifted blots, status [N])``;
+    shapes the kernels do not take are skipped as in :func:`measure_shifts`."""
     import torch
     from . import blot as _blot
     n = len(img_tiles)
     affine = np.asarray(affine, dtype=np.float64).reshape(n, 6)
     gain = None if gain is None else np.asarray(gain, dtype=np.float32).reshape(n)
-    dxdy = np.empty((n, 2), dtype=np.float64)
+    dxdy = np.zeros((n, 2), dtype=np.float64)
+    status = np.full(n, ST_SKIPPED, dtype=np.int32)
     iccs, blt00 = [None] * n, [None] * n
     groups = {}
     for k in range(n):
-        groups.setdefault((np.shape(img_tiles[k]), np.shape(drz_tiles[k])), []).append(k)
+        if _shape_ok(np.shape(img_tiles[k])) and min(np.shape(drz_tiles[k])) >= 6:
+            groups.setdefault((np.shape(img_tiles[k]), np.shape(drz_tiles[k])), []).append(k)
     for (ishape, _), idx in groups.items():
         ref = torch.as_tensor(np.stack([np.asarray(img_tiles[k], dtype=np.float32) for k in idx])).cuda()
         src = torch.as_tensor(np.stack([np.asarray(drz_tiles[k], dtype=np.float32) for k in idx])).cuda()
         im4 = _blot.blot_affine4_batch(src, affine[idx], ishape, None if gain is None else gain[idx])
-        d, icc = cc.find_displacement_batch(ref, im4, cc_type=cc_type, full_output=True)
+        d, icc, st = cc.find_displacement_batch(ref, im4, cc_type=cc_type, full_output=True,
+                                                return_status=True)
         d, icc, b0 = d.cpu().numpy(), icc.cpu().numpy(), im4[:, 0].cpu().numpy()
         dxdy[idx] = d
+        status[idx] = st.cpu().numpy()
         for j, k in enumerate(idx):
             iccs[k] = icc[j]
             blt00[k] = b0[j]
-    return dxdy, iccs, blt00
+    return dxdy, iccs, blt00, status
 
 
 def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
@@ -234,14 +271,19 @@ def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
         blts.append((b00, b10, b01, b11))
 
     if affine is not None:
-        img_dxy, interlaced_cc, nonshifted_blts = measure_shifts_affine(
+        img_dxy, interlaced_cc, nonshifted_blts, status = measure_shifts_affine(
             [data_of(c) for c in img_cutouts], [data_of(c) for c in drz_cutouts], affine, gain,
             cc_type=cc_type)
     else:
-        img_dxy, interlaced_cc = measure_shifts(
+        img_dxy, interlaced_cc, status = measure_shifts(
             [data_of(c) for c in img_cutouts],
-            [[data_of(b) for b in four] for four in blts], cc_type=cc_type, full_output=True)
+            [[data_of(b) for b in four] for four in blts], cc_type=cc_type, full_output=True,
+            return_status=True)
         nonshifted_blts = [four[0] for four in blts]
+    # Sources without a measurement (non-finite pixels, e.g. the NaN fill of a cutout overhanging
+    # its frame; an oversized cutout) get zero weight instead of poisoning the fit with a
+    # meaningless shift.  The reference has no such guard: it would fit whatever came back.
+    good = usable_status(status)
 
     xyim = np.empty((npts, 2))
     xyref = np.empty((npts, 2))
@@ -270,6 +312,9 @@ def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
             raise ValueError("Weights must be non-negative.")
         else:
             weights = np.asarray(weights, dtype=np.float64)
+    user_weights = weights is not None
+    if not np.all(good):
+        weights = (np.ones(npts) if weights is None else weights) * good
 
     center = None
     if wcslin is not None and hasattr(wcslin, 'wcs'):
@@ -278,8 +323,9 @@ def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
                           nclip=nclip, sigma=sigma)
     fit['subpixal_img_dxy'] = img_dxy
     fit['subpixal_ref_dxy'] = ref_dxy
+    fit['subpixal_status'] = status
     m = fit['fitmask']
-    if weights is None:                                                    # align.py:730-743
+    if not user_weights:                                                   # align.py:730-743
         fit['irmse'] = float(np.sqrt(2 * np.mean(img_dxy[m] ** 2)))
     else:
         wt = np.sum(weights)

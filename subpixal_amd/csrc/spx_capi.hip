@@ -11,7 +11,9 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -30,126 +32,94 @@ int hip_fail(hipError_t e, const char* what) {
         if (e__ != hipSuccess) return hip_fail(e__, #call);        \
     } while (0)
 
+// Kernel families (spx_kernels32.h / spx_kernels.h / spx_kernels128.h) and the cutout sides
+// they take.  The FFT period is the smallest the path has for which the reference's 'same'
+// window (cc.py:114-126) is alias-free: P > 2n - 2 - (n-1)/2.
+enum Tile { TILE32 = 0, TILE64 = 1, TILE192 = 2, NUM_TILES = 3 };
+constexpr int kFoldMaxSide = 85;      // 64 tile, fold path: period 128 covers cutouts up to 85 px
+Tile tile_for(int ny, int nx) {
+    const int n = ny > nx ? ny : nx;
+    return n <= 32 ? TILE32 : (n <= kFoldMaxSide ? TILE64 : TILE192);
+}
+constexpr int kPeriod[NUM_TILES] = {64, 128, 192};
+
 struct DeviceTables {
-    spx::cf* tw128 = nullptr;                 // w_128^j
-    spx::cf* tw256 = nullptr;                 // w_256^j (128 tile)
-    spx::cf* tw192 = nullptr;                 // w_192^j (96 tile)
-    spx::cf* tw64 = nullptr;                  // w_64^j (32 tile)
-    std::map<int, float*> ktab;               // upsample -> lane-major tables, 64 tile
-    std::map<int, float*> ktab256;            // upsample -> lane-major tables, 128 tile
-    std::map<int, float*> ktab192;            // upsample -> lane-major tables, 96 tile
-    std::map<int, float*> ktab32;             // upsample -> lane-major tables, 32 tile
+    bool ready = false;                          // set only after EVERY table below exists
+    spx::cf* tw[NUM_TILES] = {nullptr, nullptr, nullptr};     // w_P^j
+    std::map<int, float*> ktab[NUM_TILES];       // upsample -> lane-major interpolation tables
+    std::set<const void*> lds_ok;                // kernels whose dynamic-LDS limit is raised
     int num_cu = 256;
-    bool lds_attr_set = false;
+    std::mutex launch_mu;                        // serialises enqueues of host threads sharing a device
 };
 
-std::mutex g_mu;
+std::mutex g_mu;                                 // guards g_dev and every DeviceTables' maps
 std::map<int, DeviceTables> g_dev;
 
+int upload(const std::vector<float>& h, float** out) {
+    void* p = nullptr;
+    SPX_HIP(hipMalloc(&p, h.size() * sizeof(float)));
+    const hipError_t e = hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return hip_fail(e, "hipMemcpy(table)");
+    }
+    *out = reinterpret_cast<float*>(p);
+    return 0;
+}
+
+// tables of the calling thread's current device; built on first use.  Everything is built
+// into locals and committed together, so a failed allocation leaves no half-initialised state.
 int current_tables(DeviceTables** out) {
     int dev = 0;
     SPX_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
     DeviceTables& t = g_dev[dev];
-    if (!t.tw128) {
-        std::vector<float> tw = spx::host::make_twiddles(128);
-        void* p = nullptr;
-        SPX_HIP(hipMalloc(&p, tw.size() * sizeof(float)));
-        SPX_HIP(hipMemcpy(p, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
-        t.tw128 = reinterpret_cast<spx::cf*>(p);
-        std::vector<float> tw2 = spx::host::make_twiddles(256);
-        SPX_HIP(hipMalloc(&p, tw2.size() * sizeof(float)));
-        SPX_HIP(hipMemcpy(p, tw2.data(), tw2.size() * sizeof(float), hipMemcpyHostToDevice));
-        t.tw256 = reinterpret_cast<spx::cf*>(p);
-        std::vector<float> tw4 = spx::host::make_twiddles(192);
-        SPX_HIP(hipMalloc(&p, tw4.size() * sizeof(float)));
-        SPX_HIP(hipMemcpy(p, tw4.data(), tw4.size() * sizeof(float), hipMemcpyHostToDevice));
-        t.tw192 = reinterpret_cast<spx::cf*>(p);
-        std::vector<float> tw3 = spx::host::make_twiddles(64);
-        SPX_HIP(hipMalloc(&p, tw3.size() * sizeof(float)));
-        SPX_HIP(hipMemcpy(p, tw3.data(), tw3.size() * sizeof(float), hipMemcpyHostToDevice));
-        t.tw64 = reinterpret_cast<spx::cf*>(p);
+    if (!t.ready) {
+        float* tw[NUM_TILES] = {nullptr, nullptr, nullptr};
+        for (int k = 0; k < NUM_TILES; ++k) {
+            const int rc = upload(spx::host::make_twiddles(kPeriod[k]), &tw[k]);
+            if (rc) {
+                for (int j = 0; j < k; ++j) (void)hipFree(tw[j]);
+                return rc;
+            }
+        }
         hipDeviceProp_t prop;
-        SPX_HIP(hipGetDeviceProperties(&prop, dev));
+        const hipError_t e = hipGetDeviceProperties(&prop, dev);
+        if (e != hipSuccess) {
+            for (int j = 0; j < NUM_TILES; ++j) (void)hipFree(tw[j]);
+            return hip_fail(e, "hipGetDeviceProperties");
+        }
+        for (int k = 0; k < NUM_TILES; ++k) t.tw[k] = reinterpret_cast<spx::cf*>(tw[k]);
         t.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        t.ready = true;
     }
     *out = &t;
     return 0;
 }
 
-int ktab_for(DeviceTables* t, int upsample, const float** out) {
+// interpolation tables of one tile family for `upsample` (nullptr for upsample 1)
+int ktab_for(DeviceTables* t, Tile tile, int upsample, const float** out) {
     *out = nullptr;
     const int wb = spx::host::window_blocks(upsample);
     if (wb <= 0) return 0;
     std::lock_guard<std::mutex> lk(g_mu);
-    auto it = t->ktab.find(upsample);
-    if (it == t->ktab.end()) {
-        std::vector<float> k = spx::host::make_ktab(128, upsample, 16 * wb);
-        void* p = nullptr;
-        SPX_HIP(hipMalloc(&p, k.size() * sizeof(float)));
-        SPX_HIP(hipMemcpy(p, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
-        it = t->ktab.emplace(upsample, reinterpret_cast<float*>(p)).first;
+    auto it = t->ktab[tile].find(upsample);
+    if (it == t->ktab[tile].end()) {
+        std::vector<float> k = tile == TILE32 ? spx::host::make_ktab32(upsample, 16 * wb)
+                             : tile == TILE64 ? spx::host::make_ktab(128, upsample, 16 * wb)
+                                              : spx::host::make_ktab_big(192, upsample, 16 * wb);
+        float* p = nullptr;
+        const int rc = upload(k, &p);
+        if (rc) return rc;
+        it = t->ktab[tile].emplace(upsample, p).first;
     }
     *out = it->second;
     return 0;
 }
 
-int ktab256_for(DeviceTables* t, int upsample, const float** out) {
-    *out = nullptr;
-    const int wb = spx::host::window_blocks(upsample);
-    if (wb <= 0) return 0;
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = t->ktab256.find(upsample);
-    if (it == t->ktab256.end()) {
-        std::vector<float> k = spx::host::make_ktab256(upsample, 16 * wb);
-        void* p = nullptr;
-        SPX_HIP(hipMalloc(&p, k.size() * sizeof(float)));
-        SPX_HIP(hipMemcpy(p, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
-        it = t->ktab256.emplace(upsample, reinterpret_cast<float*>(p)).first;
-    }
-    *out = it->second;
-    return 0;
-}
-
-int ktab192_for(DeviceTables* t, int upsample, const float** out) {
-    *out = nullptr;
-    const int wb = spx::host::window_blocks(upsample);
-    if (wb <= 0) return 0;
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = t->ktab192.find(upsample);
-    if (it == t->ktab192.end()) {
-        std::vector<float> k = spx::host::make_ktab_big(192, upsample, 16 * wb);
-        void* p = nullptr;
-        SPX_HIP(hipMalloc(&p, k.size() * sizeof(float)));
-        SPX_HIP(hipMemcpy(p, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
-        it = t->ktab192.emplace(upsample, reinterpret_cast<float*>(p)).first;
-    }
-    *out = it->second;
-    return 0;
-}
-
-int ktab32_for(DeviceTables* t, int upsample, const float** out) {
-    *out = nullptr;
-    const int wb = spx::host::window_blocks(upsample);
-    if (wb <= 0) return 0;
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = t->ktab32.find(upsample);
-    if (it == t->ktab32.end()) {
-        std::vector<float> k = spx::host::make_ktab32(upsample, 16 * wb);
-        void* p = nullptr;
-        SPX_HIP(hipMalloc(&p, k.size() * sizeof(float)));
-        SPX_HIP(hipMemcpy(p, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
-        it = t->ktab32.emplace(upsample, reinterpret_cast<float*>(p)).first;
-    }
-    *out = it->second;
-    return 0;
-}
-
-// workgroups of a 128-tile launch (each owns one 772 KiB workspace slot)
-int64_t grid128(int num_cu, int64_t nbatch) {
-    // SPX_GRID128_PER_CU (tuning knob, default 2): resident workgroups per CU; each owns
-    // 772 KiB of workspace (at 2 per CU the total, 386 MiB, exceeds the 256 MiB Infinity Cache;
-    // 1 per CU fits but measured slower: too little latency hiding)
+// workgroups of a period-192 launch (each owns one workspace slot)
+int64_t grid_big(int num_cu, int64_t nbatch) {
+    // SPX_GRID128_PER_CU (tuning knob, default 2): resident workgroups per CU
     static const int per_cu = [] {
         const char* e = getenv("SPX_GRID128_PER_CU");
         const int v = e ? atoi(e) : 2;
@@ -166,9 +136,14 @@ int device_cus() {
     return n;
 }
 
-template <typename K> int allow_lds(K kernel, int bytes) {
-    SPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+// raise a kernel's dynamic-LDS limit: once per kernel instance and device (spx_prepare() does
+// it for every instance a later launch can pick, so a captured launch issues no such call)
+// (callers hold t->launch_mu)
+template <typename K> int allow_lds(DeviceTables* t, K kernel, int bytes) {
+    const void* key = reinterpret_cast<const void*>(kernel);
+    if (t->lds_ok.count(key)) return 0;
+    SPX_HIP(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    t->lds_ok.insert(key);
     return 0;
 }
 
@@ -185,49 +160,178 @@ unsigned grid_for(const DeviceTables* t, int64_t nbatch) {
     return (unsigned)(nbatch < cap ? nbatch : cap);
 }
 
-template <int WB, int DBG = 0>
-int launch_pair(const DeviceTables* t, const float* ref, const float* img, int64_t nbatch, int ny,
-                int nx, int U, int cc_type, const float* ktab, double* out, int32_t* status,
-                hipStream_t s) {
+struct PairArgs {
+    int64_t nbatch;
+    int ny, nx, U, cc_type;
+    const float* ktab;
+    double* out;
+    int32_t* status;
+    float* ws;
+    hipStream_t s;
+};
+
+// One pair-mode kernel instance: `launch` false only raises its LDS limit (spx_prepare).
+template <int WB, bool FOLD, typename TIn, int DBG = 0>
+int run_pair64(DeviceTables* t, const TIn* ref, const TIn* img, const PairArgs& a, bool launch) {
     const int lds = spx::Lds<2>::total(16 * WB);
-    auto kern = spx::pair_kernel<2, WB, DBG>;
-    int rc = allow_lds(kern, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid_for(t, nbatch)), dim3(spx::kThreads), lds, s, ref, img,
-                       nbatch, ny, nx, U, cc_type, t->tw128, ktab, out, status);
+    auto kern = spx::pair_kernel<2, WB, DBG, FOLD, TIn>;
+    int rc = allow_lds(t, kern, lds);
+    if (rc || !launch) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid_for(t, a.nbatch)), dim3(spx::kThreads), lds, a.s, ref, img,
+                       a.nbatch, a.ny, a.nx, a.U, a.cc_type, t->tw[TILE64], a.ktab, a.out, a.status);
     SPX_HIP(hipGetLastError());
     return 0;
 }
-
 // 32 tile: one wave per pair, four pairs per workgroup
-template <int WB>
-int launch_pair32(const DeviceTables* t, const float* ref, const float* img, int64_t nbatch, int ny,
-                  int nx, int U, int cc_type, const float* ktab, double* out, int32_t* status,
-                  hipStream_t s) {
+template <int WB, typename TIn>
+int run_pair32(DeviceTables* t, const TIn* ref, const TIn* img, const PairArgs& a, bool launch) {
     const int lds = spx::Lds32::total(16 * (WB > 0 ? WB : 1));
-    auto kern = spx::pair32_kernel<WB>;
-    int rc = allow_lds(kern, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid_for(t, (nbatch + 3) / 4)), dim3(spx::kThreads), lds, s, ref,
-                       img, nbatch, ny, nx, U, cc_type, t->tw64, ktab, out, status);
+    auto kern = spx::pair32_kernel<WB, TIn>;
+    int rc = allow_lds(t, kern, lds);
+    if (rc || !launch) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid_for(t, (a.nbatch + 3) / 4)), dim3(spx::kThreads), lds, a.s, ref,
+                       img, a.nbatch, a.ny, a.nx, a.U, a.cc_type, t->tw[TILE32], a.ktab, a.out, a.status);
+    SPX_HIP(hipGetLastError());
+    return 0;
+}
+// period 192 (9 spectral classes, per-workgroup workspace)
+template <int WB, typename TIn, int DBG = 0>
+int run_pair192(DeviceTables* t, const TIn* ref, const TIn* img, const PairArgs& a, bool launch) {
+    const int lds = spx::LdsBig<3>::total(16 * WB);
+    auto kern = spx::pair128_kernel<3, WB, DBG, TIn>;
+    int rc = allow_lds(t, kern, lds);
+    if (rc || !launch) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid_big(t->num_cu, a.nbatch)), dim3(spx::kThreads), lds, a.s,
+                       ref, img, a.nbatch, a.ny, a.nx, a.U, a.cc_type, t->tw[TILE192], a.ktab, a.out,
+                       a.status, a.ws);
     SPX_HIP(hipGetLastError());
     return 0;
 }
 
-// C = 4: 128 tile (period 256), C = 3: 96 tile (period 192)
-template <int C, int WB, int DBG = 0>
-int launch_pair128(const DeviceTables* t, const float* ref, const float* img, int64_t nbatch, int ny,
-                   int nx, int U, int cc_type, const float* ktab, double* out, int32_t* status,
-                   float* ws, hipStream_t s) {
-    const int lds = spx::LdsBig<C>::total(16 * WB);
-    auto kern = spx::pair128_kernel<C, WB, DBG>;
-    int rc = allow_lds(kern, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid128(t->num_cu, nbatch)), dim3(spx::kThreads), lds, s,
-                       ref, img, nbatch, ny, nx, U, cc_type, C == 4 ? t->tw256 : t->tw192, ktab, out,
-                       status, ws);
+template <int WB, typename TIn>
+int run_pair_wb(DeviceTables* t, Tile tile, bool fold, const TIn* ref, const TIn* img,
+                const PairArgs& a, bool launch) {
+    switch (tile) {
+    case TILE32: return run_pair32<WB, TIn>(t, ref, img, a, launch);
+    case TILE64: return fold ? run_pair64<WB, true, TIn>(t, ref, img, a, launch)
+                             : run_pair64<WB, false, TIn>(t, ref, img, a, launch);
+    default: return run_pair192<WB, TIn>(t, ref, img, a, launch);
+    }
+}
+template <typename TIn>
+int run_pair(DeviceTables* t, int wb, Tile tile, bool fold, const TIn* ref, const TIn* img,
+             const PairArgs& a, bool launch) {
+    switch (wb) {
+    case 0: return run_pair_wb<0, TIn>(t, tile, fold, ref, img, a, launch);
+    case 1: return run_pair_wb<1, TIn>(t, tile, fold, ref, img, a, launch);
+    case 2: return run_pair_wb<2, TIn>(t, tile, fold, ref, img, a, launch);
+    case 3: return run_pair_wb<3, TIn>(t, tile, fold, ref, img, a, launch);
+    default: return run_pair_wb<4, TIn>(t, tile, fold, ref, img, a, launch);
+    }
+}
+
+struct Disp5Args {
+    int64_t nbatch;
+    int ny, nx, cc_type;
+    float* icc;
+    double* out;
+    int32_t* status;
+    float* ws;
+    hipStream_t s;
+};
+template <typename TIn>
+int run_disp5(DeviceTables* t, Tile tile, bool fold, const TIn* ref, const TIn* im4,
+              const Disp5Args& a, bool launch) {
+    if (tile == TILE192) {
+        const int lds = spx::LdsBig<3>::total(0);
+        auto kern = spx::disp5_128_kernel<3, TIn>;
+        int rc = allow_lds(t, kern, lds);
+        if (rc || !launch) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid_big(t->num_cu, a.nbatch)), dim3(spx::kThreads), lds,
+                           a.s, ref, im4, a.nbatch, a.ny, a.nx, a.cc_type, t->tw[TILE192], a.icc, a.out,
+                           a.status, a.ws);
+        SPX_HIP(hipGetLastError());
+        return 0;
+    }
+    if (tile == TILE32) {
+        const int lds = spx::Lds32::total(16);
+        auto kern = spx::disp5_32_kernel<TIn>;
+        int rc = allow_lds(t, kern, lds);
+        if (rc || !launch) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid_for(t, (a.nbatch + 3) / 4)), dim3(spx::kThreads), lds, a.s, ref,
+                           im4, a.nbatch, a.ny, a.nx, a.cc_type, t->tw[TILE32], a.icc, a.out, a.status);
+        SPX_HIP(hipGetLastError());
+        return 0;
+    }
+    const int lds = spx::Lds<2>::total(0);
+    auto kern = fold ? spx::disp5_kernel<2, true, TIn> : spx::disp5_kernel<2, false, TIn>;
+    int rc = allow_lds(t, kern, lds);
+    if (rc || !launch) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid_for(t, a.nbatch)), dim3(spx::kThreads), lds, a.s, ref, im4, a.nbatch,
+                       a.ny, a.nx, a.cc_type, t->tw[TILE64], a.icc, a.out, a.status);
     SPX_HIP(hipGetLastError());
     return 0;
+}
+
+size_t ws_bytes_xcorr(int64_t nbatch, int ny, int nx) {
+    if (nbatch <= 0 || ny <= 0 || nx <= 0) return 0;
+    if (tile_for(ny, nx) != TILE192) return 0;
+    return (size_t)grid_big(device_cus(), nbatch) * spx::kWs96Bytes;
+}
+
+template <typename TIn>
+int xcorr_refine(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx, int upsample,
+                 int cc_type, double* out_dxdy, int32_t* out_status, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+    if (nbatch < 0 || (nbatch > 0 && (!ref || !img || !out_dxdy)))
+        return fail(SPX_E_ARG, "null pointer or negative batch");
+    if (ny < 5 || nx < 5 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
+        return fail(SPX_E_SHAPE, "pair mode supports cutouts of 5..128 pixels per side");
+    const int wb = spx::host::window_blocks(upsample);
+    if (wb < 0) return fail(SPX_E_SHAPE, "upsample must be in [1, 59]");
+    if (nbatch == 0) return 0;
+    const Tile tile = tile_for(ny, nx);
+    if (tile == TILE192 && (!workspace || workspace_bytes < ws_bytes_xcorr(nbatch, ny, nx)))
+        return fail(SPX_E_WORKSPACE, "cutouts above 85 px need spx_workspace_bytes_xcorr() bytes");
+    DeviceTables* t = nullptr;
+    int rc = current_tables(&t);
+    if (rc) return rc;
+    PairArgs a;
+    a.nbatch = nbatch; a.ny = ny; a.nx = nx; a.U = upsample; a.cc_type = cc_type;
+    a.out = out_dxdy; a.status = out_status;
+    a.ws = reinterpret_cast<float*>(workspace);
+    a.s = reinterpret_cast<hipStream_t>(stream);
+    rc = ktab_for(t, tile, upsample, &a.ktab);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(t->launch_mu);
+    return run_pair<TIn>(t, wb, tile, ny > 64 || nx > 64, ref, img, a, true);
+}
+
+template <typename TIn>
+int find_displacement5(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, int nx, int cc_type,
+                       double* out_dxdy, int32_t* out_status, float* out_icc, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    if (nbatch < 0 || (nbatch > 0 && (!ref || !im4 || !out_dxdy)))
+        return fail(SPX_E_ARG, "null pointer or negative batch");
+    if (ny < 3 || nx < 3 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
+        return fail(SPX_E_SHAPE, "5-image mode supports cutouts of 3..128 pixels per side");
+    if (nbatch == 0) return 0;
+    const size_t need = spx_workspace_bytes_displacement5(nbatch, ny, nx, out_icc == nullptr);
+    if (need > 0 && (!workspace || workspace_bytes < need))
+        return fail(SPX_E_WORKSPACE, "workspace missing or smaller than spx_workspace_bytes_displacement5()");
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
+    const size_t tile_ws = ws_bytes_xcorr(nbatch, ny, nx);
+    DeviceTables* t = nullptr;
+    int rc = current_tables(&t);
+    if (rc) return rc;
+    Disp5Args a;
+    a.nbatch = nbatch; a.ny = ny; a.nx = nx; a.cc_type = cc_type;
+    a.icc = out_icc ? out_icc : reinterpret_cast<float*>(wsb + tile_ws);
+    a.out = out_dxdy; a.status = out_status;
+    a.ws = reinterpret_cast<float*>(wsb);
+    a.s = reinterpret_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> lk(t->launch_mu);
+    return run_disp5<TIn>(t, tile_for(ny, nx), ny > 64 || nx > 64, ref, im4, a, true);
 }
 
 }  // namespace
@@ -251,31 +355,64 @@ int spx_init(int device) {
 }
 
 int spx_prepare(int upsample) {
-    if (spx::host::window_blocks(upsample) < 0)
-        return fail(SPX_E_SHAPE, "upsample must be in [1, 59]");
+    const int wb = spx::host::window_blocks(upsample);
+    if (wb < 0) return fail(SPX_E_SHAPE, "upsample must be in [1, 59]");
     DeviceTables* t = nullptr;
     int rc = current_tables(&t);
     if (rc) return rc;
-    const float* k = nullptr;
-    return ktab_for(t, upsample, &k);
+    PairArgs pa = {};
+    Disp5Args da = {};
+    for (int k = 0; k < NUM_TILES; ++k) {
+        const float* kt = nullptr;
+        if ((rc = ktab_for(t, (Tile)k, upsample, &kt))) return rc;
+    }
+    for (int k = 0; k < NUM_TILES; ++k) {
+        std::lock_guard<std::mutex> lk(t->launch_mu);
+        const Tile tile = (Tile)k;
+        for (int fold = 0; fold < (tile == TILE64 ? 2 : 1); ++fold) {
+            if ((rc = run_pair<float>(t, wb, tile, fold != 0, nullptr, nullptr, pa, false))) return rc;
+            if ((rc = run_pair<double>(t, wb, tile, fold != 0, nullptr, nullptr, pa, false))) return rc;
+            if ((rc = run_disp5<float>(t, tile, fold != 0, nullptr, nullptr, da, false))) return rc;
+            if ((rc = run_disp5<double>(t, tile, fold != 0, nullptr, nullptr, da, false))) return rc;
+        }
+    }
+    return 0;
 }
 
-size_t spx_workspace_bytes_xcorr(int64_t nbatch, int ny, int nx) {
-    if (nbatch <= 0 || ny <= 0 || nx <= 0) return 0;
-    if (ny <= 64 && nx <= 64) return 0;
-    const size_t per_group = (ny <= 96 && nx <= 96) ? spx::kWs96Bytes : spx::kWs128Bytes;
-    return (size_t)grid128(device_cus(), nbatch) * per_group;
+int spx_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    int rc = 0;
+    for (auto& kv : g_dev) {
+        DeviceTables& t = kv.second;
+        std::lock_guard<std::mutex> ll(t.launch_mu);
+        if (hipSetDevice(kv.first) != hipSuccess) { rc = SPX_E_HIP; continue; }
+        if (hipDeviceSynchronize() != hipSuccess) rc = SPX_E_HIP;      // no launch may still read a table
+        for (int k = 0; k < NUM_TILES; ++k) {
+            if (t.tw[k]) (void)hipFree(t.tw[k]);
+            t.tw[k] = nullptr;
+            for (auto& e : t.ktab[k]) (void)hipFree(e.second);
+            t.ktab[k].clear();
+        }
+        t.ready = false;
+    }
+    if (have_prev) (void)hipSetDevice(prev);
+    if (rc) return fail(rc, "spx_shutdown: a device could not be synchronised");
+    return 0;
 }
 
-// the phase-stamp diagnostic runs on the 128 tile whatever the shape
-static size_t workspace_bytes_tile128(int64_t nbatch, int ny, int nx) {
-    if (nbatch <= 0 || (ny <= 64 && nx <= 64)) return 0;
-    return (size_t)grid128(device_cus(), nbatch) * spx::kWs128Bytes;
+size_t spx_workspace_bytes_xcorr(int64_t nbatch, int ny, int nx) { return ws_bytes_xcorr(nbatch, ny, nx); }
+
+// the phase-stamp diagnostic runs on the period-192 path whatever the shape
+static size_t workspace_bytes_big(int64_t nbatch) {
+    if (nbatch <= 0) return 0;
+    return (size_t)grid_big(device_cus(), nbatch) * spx::kWs96Bytes;
 }
 
 size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int need_icc) {
     if (nbatch <= 0 || ny <= 0 || nx <= 0) return 0;
-    size_t b = spx_workspace_bytes_xcorr(nbatch, ny, nx);
+    size_t b = ws_bytes_xcorr(nbatch, ny, nx);
     if (need_icc) b += (size_t)nbatch * 4u * (size_t)ny * (size_t)nx * sizeof(float);
     return b;
 }
@@ -283,67 +420,14 @@ size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int nee
 int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
                          int upsample, int cc_type, double* out_dxdy, int32_t* out_status,
                          void* workspace, size_t workspace_bytes, void* stream) {
-    if (nbatch < 0 || (nbatch > 0 && (!ref || !img || !out_dxdy)))
-        return fail(SPX_E_ARG, "null pointer or negative batch");
-    if (ny < 5 || nx < 5 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
-        return fail(SPX_E_SHAPE, "pair mode supports cutouts of 5..128 pixels per side");
-    const int wb = spx::host::window_blocks(upsample);
-    if (wb < 0) return fail(SPX_E_SHAPE, "upsample must be in [1, 59]");
-    if (nbatch == 0) return 0;
-    const bool big = ny > 64 || nx > 64;            // 96 / 128 tile, FFT period 192 / 256
-    if (big && (!workspace || workspace_bytes < spx_workspace_bytes_xcorr(nbatch, ny, nx)))
-        return fail(SPX_E_WORKSPACE, "cutouts above 64 px need spx_workspace_bytes_xcorr() bytes");
-    DeviceTables* t = nullptr;
-    int rc = current_tables(&t);
-    if (rc) return rc;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (big && ny <= 96 && nx <= 96) {
-        const float* ktab = nullptr;
-        rc = ktab192_for(t, upsample, &ktab);
-        if (rc) return rc;
-        float* ws = reinterpret_cast<float*>(workspace);
-        switch (wb) {
-        case 0: return launch_pair128<3, 0>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
-        case 1: return launch_pair128<3, 1>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
-        case 2: return launch_pair128<3, 2>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
-        case 3: return launch_pair128<3, 3>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
-        default: return launch_pair128<3, 4>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
-        }
-    }
-    if (big) {
-        const float* ktab = nullptr;
-        rc = ktab256_for(t, upsample, &ktab);
-        if (rc) return rc;
-        float* ws = reinterpret_cast<float*>(workspace);
-        switch (wb) {
-        case 0: return launch_pair128<4, 0>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
-        case 1: return launch_pair128<4, 1>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
-        case 2: return launch_pair128<4, 2>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
-        case 3: return launch_pair128<4, 3>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
-        default: return launch_pair128<4, 4>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, ws, s);
-        }
-    }
-    const float* ktab = nullptr;
-    if (ny <= 32 && nx <= 32) {                     // 32 tile, FFT period 64
-        rc = ktab32_for(t, upsample, &ktab);
-        if (rc) return rc;
-        switch (wb) {
-        case 0: return launch_pair32<0>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
-        case 1: return launch_pair32<1>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
-        case 2: return launch_pair32<2>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
-        case 3: return launch_pair32<3>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
-        default: return launch_pair32<4>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
-        }
-    }
-    rc = ktab_for(t, upsample, &ktab);
-    if (rc) return rc;
-    switch (wb) {
-    case 0: return launch_pair<0>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
-    case 1: return launch_pair<1>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
-    case 2: return launch_pair<2>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
-    case 3: return launch_pair<3>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
-    default: return launch_pair<4>(t, ref, img, nbatch, ny, nx, upsample, cc_type, ktab, out_dxdy, out_status, s);
-    }
+    return xcorr_refine<float>(ref, img, nbatch, ny, nx, upsample, cc_type, out_dxdy, out_status,
+                               workspace, workspace_bytes, stream);
+}
+int spx_xcorr_refine_f64(const double* ref, const double* img, int64_t nbatch, int ny, int nx,
+                         int upsample, int cc_type, double* out_dxdy, int32_t* out_status,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    return xcorr_refine<double>(ref, img, nbatch, ny, nx, upsample, cc_type, out_dxdy, out_status,
+                                workspace, workspace_bytes, stream);
 }
 
 #ifdef SPX_PHASE_TIMING
@@ -356,11 +440,14 @@ int spx_diag_pair_phase(const float* ref, const float* img, int64_t nbatch, int 
     DeviceTables* t = nullptr;
     int rc = current_tables(&t);
     if (rc) return rc;
-    const float* ktab = nullptr;
-    rc = ktab_for(t, 10, &ktab);
+    PairArgs a;
+    a.nbatch = nbatch; a.ny = ny; a.nx = nx; a.U = 10; a.cc_type = 0; a.out = out_dxdy;
+    a.status = out_status; a.ws = nullptr; a.s = reinterpret_cast<hipStream_t>(stream);
+    rc = ktab_for(t, TILE64, 10, &a.ktab);
     if (rc) return rc;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define SPX_PH(k) case k: return launch_pair<1, k>(t, ref, img, nbatch, ny, nx, 10, 0, ktab, out_dxdy, out_status, s);
+    const bool fold = ny > 64 || nx > 64;
+#define SPX_PH(k) case k: return fold ? run_pair64<1, true, float, k>(t, ref, img, a, true) \
+                                      : run_pair64<1, false, float, k>(t, ref, img, a, true);
     switch (phase) {
         SPX_PH(0) SPX_PH(1) SPX_PH(2) SPX_PH(3) SPX_PH(4) SPX_PH(5) SPX_PH(6) SPX_PH(7)
         SPX_PH(8) SPX_PH(9) SPX_PH(10) SPX_PH(11) SPX_PH(12) SPX_PH(13) SPX_PH(100)
@@ -369,71 +456,38 @@ int spx_diag_pair_phase(const float* ref, const float* img, int64_t nbatch, int 
     return fail(SPX_E_ARG, "bad phase");
 }
 
-// same for the 128 tile at upsample 20 (full kernel with per-phase stamps only)
+// same for the period-192 path at upsample 20 (full kernel with per-phase stamps only)
 int spx_diag_pair128_phase(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
                            double* out_dxdy, int32_t* out_status, void* workspace,
                            size_t workspace_bytes, void* stream) {
     DeviceTables* t = nullptr;
     int rc = current_tables(&t);
     if (rc) return rc;
-    if (workspace_bytes < workspace_bytes_tile128(nbatch, ny, nx)) return fail(SPX_E_WORKSPACE, "workspace");
-    const float* ktab = nullptr;
-    rc = ktab256_for(t, 20, &ktab);
+    if (workspace_bytes < workspace_bytes_big(nbatch)) return fail(SPX_E_WORKSPACE, "workspace");
+    PairArgs a;
+    a.nbatch = nbatch; a.ny = ny; a.nx = nx; a.U = 20; a.cc_type = 0; a.out = out_dxdy;
+    a.status = out_status; a.ws = reinterpret_cast<float*>(workspace);
+    a.s = reinterpret_cast<hipStream_t>(stream);
+    rc = ktab_for(t, TILE192, 20, &a.ktab);
     if (rc) return rc;
-    return launch_pair128<4, 2, 100>(t, ref, img, nbatch, ny, nx, 20, 0, ktab, out_dxdy, out_status,
-                                  reinterpret_cast<float*>(workspace), reinterpret_cast<hipStream_t>(stream));
+    return run_pair192<2, float, 100>(t, ref, img, a, true);
 }
+size_t spx_diag_workspace_bytes_big(int64_t nbatch) { return workspace_bytes_big(nbatch); }
 #endif
 
 int spx_find_displacement5_f32(const float* ref, const float* im4, int64_t nbatch, int ny,
                                int nx, int cc_type, double* out_dxdy, int32_t* out_status,
                                float* out_icc, void* workspace, size_t workspace_bytes,
                                void* stream) {
-    if (nbatch < 0 || (nbatch > 0 && (!ref || !im4 || !out_dxdy)))
-        return fail(SPX_E_ARG, "null pointer or negative batch");
-    if (ny < 3 || nx < 3 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
-        return fail(SPX_E_SHAPE, "5-image mode supports cutouts of 3..128 pixels per side");
-    if (nbatch == 0) return 0;
-    const size_t need = spx_workspace_bytes_displacement5(nbatch, ny, nx, out_icc == nullptr);
-    if (need > 0 && (!workspace || workspace_bytes < need))
-        return fail(SPX_E_WORKSPACE, "workspace missing or smaller than spx_workspace_bytes_displacement5()");
-    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
-    const size_t tile_ws = spx_workspace_bytes_xcorr(nbatch, ny, nx);
-    float* icc = out_icc ? out_icc : reinterpret_cast<float*>(wsb + tile_ws);
-    DeviceTables* t = nullptr;
-    int rc = current_tables(&t);
-    if (rc) return rc;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (ny > 64 || nx > 64) {
-        const int lds = spx::Lds128::total(0);
-        const bool t96 = ny <= 96 && nx <= 96;          // 96 tile (period 192), else 128 tile
-        auto kern = t96 ? spx::disp5_128_kernel<3> : spx::disp5_128_kernel<4>;
-        rc = allow_lds(kern, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid128(t->num_cu, nbatch)), dim3(spx::kThreads), lds, s,
-                           ref, im4, nbatch, ny, nx, cc_type, t96 ? t->tw192 : t->tw256, icc, out_dxdy,
-                           out_status, reinterpret_cast<float*>(wsb));
-        SPX_HIP(hipGetLastError());
-        return 0;
-    }
-    if (ny <= 32 && nx <= 32) {
-        const int lds32 = spx::Lds32::total(16);
-        auto k32 = spx::disp5_32_kernel;
-        rc = allow_lds(k32, lds32);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k32, dim3(grid_for(t, (nbatch + 3) / 4)), dim3(spx::kThreads), lds32, s, ref, im4,
-                           nbatch, ny, nx, cc_type, t->tw64, icc, out_dxdy, out_status);
-        SPX_HIP(hipGetLastError());
-        return 0;
-    }
-    const int lds = spx::Lds<2>::total(0);
-    auto kern = spx::disp5_kernel<2>;
-    rc = allow_lds(kern, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid_for(t, nbatch)), dim3(spx::kThreads), lds, s, ref, im4, nbatch,
-                       ny, nx, cc_type, t->tw128, icc, out_dxdy, out_status);
-    SPX_HIP(hipGetLastError());
-    return 0;
+    return find_displacement5<float>(ref, im4, nbatch, ny, nx, cc_type, out_dxdy, out_status, out_icc,
+                                     workspace, workspace_bytes, stream);
+}
+int spx_find_displacement5_f64(const double* ref, const double* im4, int64_t nbatch, int ny,
+                               int nx, int cc_type, double* out_dxdy, int32_t* out_status,
+                               float* out_icc, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    return find_displacement5<double>(ref, im4, nbatch, ny, nx, cc_type, out_dxdy, out_status, out_icc,
+                                      workspace, workspace_bytes, stream);
 }
 
 int spx_find_peak_f64(const double* image, const uint8_t* mask, const double* guess,

@@ -52,7 +52,9 @@ constexpr int kThreads = 256;
 // hoisted out of the per-pair loop and kept -- i.e. spilled -- for the whole kernel.
 SPX_DEVICE int fresh_tid() { return rt::launder_lane(rt::thread_id()); }
 
-enum { ST_OK = 0, ST_EDGE = 1, ST_NOMAX = 2, ST_OUTSIDE = 3, ST_WINDOW = 4, ST_FEWPTS = 5 };
+enum { ST_OK = 0, ST_EDGE = 1, ST_NOMAX = 2, ST_OUTSIDE = 3, ST_WINDOW = 4, ST_FEWPTS = 5, ST_NONFINITE = 6 };
+// index of an arg-max that saw no comparable value (NaN everywhere)
+constexpr int kNoIndex = 0x7fffffff;
 enum { CC_PLAIN = 0, CC_NCC = 1, CC_ZNCC = 2 };
 
 // ---------------------------------------------------------------------------
@@ -409,23 +411,65 @@ SPX_DEVICE float warm_next_pair(const float* __restrict__ ref, const float* __re
 // with cc.py:131-156's normalisation (pool = this one image, or the `npool`
 // images of the 5-image mode whose statistics the caller passes in).
 // ---------------------------------------------------------------------------
-struct NormStats {      // what _normalize applies: im = (im - mean)/std on im != 0
-    float im_mean, im_std, ref_mean, ref_std;
+// what _normalize applies: im = (im - mean)/std on im != 0, in the INPUT's own type (the
+// reference computes in the input dtype, cc.py:135-154: for float64 cutouts the mask, mean, std
+// and the normalised pixels are float64, and only then are the pixels rounded to float32 for
+// the transforms)
+template <typename T> struct NormStatsT {
+    T im_mean, im_std, ref_mean, ref_std;
     int active;         // 0: plain CC
 };
 
+// Input element types: float32 (the type BASELINE.json measures) and float64 (read, masked and
+// normalised as float64, then rounded to float32).  Four consecutive pixels starting at p,
+// 16-byte loads that only need the element's own alignment.
+template <typename T> struct Quad { T v[4]; };
+struct __attribute__((packed, aligned(4))) PackedF4 { float v[4]; };
+struct __attribute__((packed, aligned(8))) PackedD2 { double v[2]; };
+SPX_DEVICE Quad<float> load_quad(const float* p) {
+    const PackedF4 t = *reinterpret_cast<const PackedF4*>(p);
+    return Quad<float>{{t.v[0], t.v[1], t.v[2], t.v[3]}};
+}
+SPX_DEVICE Quad<double> load_quad(const double* p) {
+    const PackedD2 a = *reinterpret_cast<const PackedD2*>(p);
+    const PackedD2 b = *reinterpret_cast<const PackedD2*>(p + 2);
+    return Quad<double>{{a.v[0], a.v[1], b.v[0], b.v[1]}};
+}
+// one image pixel / one reference pixel as staged (cc.py:144-154)
+template <typename T> SPX_DEVICE float norm_im(T m, const NormStatsT<T>& ns) {
+    if (m != (T)0) { m = m - ns.im_mean; m = m / ns.im_std; }     // masked pixels only
+    return (float)m;
+}
+template <typename T> SPX_DEVICE float norm_ref(T r, const NormStatsT<T>& ns) {
+    r = r - ns.ref_mean;                                          // all pixels
+    return (float)(r / ns.ref_std);
+}
+
+// Staged-input geometry.  Cutouts up to 64 px: 64 rows of ZS = 72 floats.  FOLD (65..85 px,
+// the period-128 transform of a cutout longer than half the period): the whole cutout plus
+// zero padding in an 88 x 88 region of row stride 88 (8 consecutive columns of 8 consecutive
+// rows fall into 64 distinct banks for both strides); the four parity classes then read
+// z[y][x] +- z[y][x+64] +- z[y+64][x] +- z[y+64][x+64] (cc_planes).
+template <int C, bool FOLD> struct StageGeom {
+    static constexpr int ZS = FOLD ? 88 : Lds<C>::ZS;
+    static constexpr int ROWS = FOLD ? 88 : 64;
+    static constexpr int CHUNKS = (FOLD ? 88 : 64) / 4;        // 4-pixel chunks per staged row
+    static_assert(2 * ROWS * ZS * 4 <= Lds<C>::XCH_BYTES || !FOLD, "fold staging must fit the exchange region");
+};
+
 // ssq[0] += sum ref^2, ssq[1] += sum img^2 over this thread's pixels (as staged).
-template <int C>
-SPX_DEVICE void stage_pair(unsigned char* lds, const float* __restrict__ ref,
-                           const float* __restrict__ img, int ny, int nx,
-                           const NormStats& ns, float (&ssq)[2]) {
+template <int C, bool FOLD = false, typename TIn = float>
+SPX_DEVICE void stage_pair(unsigned char* lds, const TIn* __restrict__ ref,
+                           const TIn* __restrict__ img, int ny, int nx,
+                           const NormStatsT<TIn>& ns, float (&ssq)[2]) {
     typedef Lds<C> L;
+    typedef StageGeom<C, FOLD> G;
     float sr = 0.0f, sm = 0.0f;
     const int tid = fresh_tid();
     float* zre = reinterpret_cast<float*>(lds + L::R_OFF);
-    float* zim = zre + 64 * L::ZS;
+    float* zim = zre + G::ROWS * G::ZS;
     const bool aligned = ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(img)) & 15) == 0;
-    if (ny == 64 && nx == 64 && aligned) {
+    if constexpr (!FOLD && sizeof(TIn) == 4) if (ny == 64 && nx == 64 && aligned) {
         // full tiles: 16-byte global loads (coalesced 1 KiB per wave-instruction) and
         // 16-byte LDS stores; the image row is read back to front for the flip
         const f32x4* r4 = reinterpret_cast<const f32x4*>(ref);
@@ -440,9 +484,8 @@ SPX_DEVICE void stage_pair(unsigned char* lds, const float* __restrict__ ref,
             if (ns.active) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (m[e] != 0.0f) { m[e] = m[e] - ns.im_mean; m[e] = m[e] / ns.im_std; }
-                    r[e] = r[e] - ns.ref_mean;
-                    r[e] = r[e] / ns.ref_std;
+                    m[e] = norm_im(m[e], ns);
+                    r[e] = norm_ref(r[e], ns);
                 }
             }
             *reinterpret_cast<f32x4*>(zre + y * L::ZS + x4) = r;
@@ -457,39 +500,40 @@ SPX_DEVICE void stage_pair(unsigned char* lds, const float* __restrict__ ref,
     // every other shape: 4-pixel chunks, one 16-byte load each (4-byte aligned is enough on
     // gfx950) when the chunk lies inside its row, element loads for the chunk that straddles
     // the row end, zeros in the padding; the image is read back to front (cc.py:114)
-    struct __attribute__((packed, aligned(4))) U4 { float v[4]; };
+    constexpr int kIters = (G::ROWS * G::CHUNKS + kThreads - 1) / kThreads;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kIters; ++i) {
         const int idx = tid + i * kThreads;
-        const int y = idx >> 4, x = (idx & 15) << 2;
+        if (FOLD && idx >= G::ROWS * G::CHUNKS) break;
+        const int y = FOLD ? idx / G::CHUNKS : idx >> 4;
+        const int x = (FOLD ? idx - y * G::CHUNKS : (idx & 15)) << 2;
         float rr[4] = {0.f, 0.f, 0.f, 0.f}, mm[4] = {0.f, 0.f, 0.f, 0.f};
         if (y < ny && x < nx) {
-            const float* rrow = ref + (int64_t)y * nx + x;
-            const float* mrow = img + (int64_t)(ny - 1 - y) * nx + (nx - 1 - x);
+            const TIn* rrow = ref + (int64_t)y * nx + x;
+            const TIn* mrow = img + (int64_t)(ny - 1 - y) * nx + (nx - 1 - x);
+            TIn ri[4] = {0, 0, 0, 0}, mi[4] = {0, 0, 0, 0};
             if (x + 3 < nx) {
-                const U4 r = *reinterpret_cast<const U4*>(rrow);
-                const U4 t = *reinterpret_cast<const U4*>(mrow - 3);
+                const Quad<TIn> r = load_quad(rrow);
+                const Quad<TIn> t = load_quad(mrow - 3);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { rr[e] = r.v[e]; mm[e] = t.v[3 - e]; }
+                for (int e = 0; e < 4; ++e) { ri[e] = r.v[e]; mi[e] = t.v[3 - e]; }
             } else {
-                for (int e = 0; e < 4 && x + e < nx; ++e) { rr[e] = rrow[e]; mm[e] = mrow[-e]; }
+                for (int e = 0; e < 4 && x + e < nx; ++e) { ri[e] = rrow[e]; mi[e] = mrow[-e]; }
             }
             const int nin = nx - x < 4 ? nx - x : 4;          // pixels of the chunk inside the cutout
-            if (ns.active) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (e < nin) {
-                        if (mm[e] != 0.0f) {           // cc.py:144-148: masked pixels only
-                            mm[e] = mm[e] - ns.im_mean;
-                            mm[e] = mm[e] / ns.im_std;
-                        }
-                        rr[e] = rr[e] - ns.ref_mean;   // cc.py:153-154: all pixels
-                        rr[e] = rr[e] / ns.ref_std;
-                    }
+            for (int e = 0; e < 4; ++e) {
+                if (ns.active && e < nin) {
+                    mm[e] = norm_im(mi[e], ns);        // cc.py:144-148: masked pixels only
+                    rr[e] = norm_ref(ri[e], ns);       // cc.py:153-154: all pixels
+                } else {
+                    mm[e] = (float)mi[e];
+                    rr[e] = (float)ri[e];
+                }
             }
         }
-        *reinterpret_cast<f32x4*>(zre + y * L::ZS + x) = f32x4{rr[0], rr[1], rr[2], rr[3]};
-        *reinterpret_cast<f32x4*>(zim + y * L::ZS + x) = f32x4{mm[0], mm[1], mm[2], mm[3]};
+        *reinterpret_cast<f32x4*>(zre + y * G::ZS + x) = f32x4{rr[0], rr[1], rr[2], rr[3]};
+        *reinterpret_cast<f32x4*>(zim + y * G::ZS + x) = f32x4{mm[0], mm[1], mm[2], mm[3]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sr += rr[e] * rr[e]; sm += mm[e] * mm[e]; }
     }
@@ -499,15 +543,21 @@ SPX_DEVICE void stage_pair(unsigned char* lds, const float* __restrict__ ref,
 
 // Z = FFT(ref + i*bal*flip(img)) is squared, so the cross term 2 ref*img is rounded
 // relative to ref*ref + img*img: keep the two images at comparable amplitude.  `bal`
-// is an exact power of two near sqrt(sum ref^2 / sum img^2) (1 when either is zero);
-// results are multiplied by 1/bal, also exact.  Workgroup-wide; one barrier.
+// is an exact power of two within a factor 2 of sqrt(sum ref^2 / sum img^2) (1 when either
+// is zero); results are multiplied by 1/bal, also exact.  Workgroup-wide; one barrier.
+// bal = 2^floor((E0 - E1)/2) from the exponent fields alone (no division, no overflow
+// of the ratio: counts against counts/s may differ by 1e30 and more), clamped to 2^+-100.
+SPX_DEVICE float balance_from_ssq(float s0, float s1) {
+    if (!(s0 > 0.0f) || !(s1 > 0.0f)) return 1.0f;
+    const int e0 = (int)((__builtin_bit_cast(unsigned, s0) >> 23) & 0xffu);
+    const int e1 = (int)((__builtin_bit_cast(unsigned, s1) >> 23) & 0xffu);
+    int e = (e0 - e1) >> 1;
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    return __builtin_bit_cast(float, (unsigned)(127 + e) << 23);
+}
 SPX_DEVICE float balance_factor(unsigned char* lds_scr, float (&ssq)[2]) {
     block_sum2f(lds_scr, ssq[0], ssq[1]);
-    if (!(ssq[0] > 0.0f) || !(ssq[1] > 0.0f)) return 1.0f;
-    const float ratio = __builtin_sqrtf(ssq[0] / ssq[1]);
-    if (!(ratio > 1e-30f && ratio < 1e30f)) return 1.0f;
-    // largest power of two <= ratio: keep the exponent field, clear the mantissa
-    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, ratio) & 0x7f800000u);
+    return balance_from_ssq(ssq[0], ssq[1]);
 }
 
 // Physical column of plane element (row, col): an XOR swizzle on column bits 3-4 by the
@@ -538,9 +588,10 @@ SPX_DEVICE float fold_tile(cf (&v)[8][8]) {
 // cc_planes: staged input planes -> the NCLS real class planes d_c in LDS.
 // Caller must have issued a block_sync after staging; ends with a block_sync.
 // ---------------------------------------------------------------------------
-template <int C, int DBG = 0>
+template <int C, int DBG = 0, bool FOLD = false>
 SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, int rot = 0) {
     typedef Lds<C> L;
+    typedef StageGeom<C, FOLD> G;
     static_assert(C == 2, "class decomposition implemented for P = 128");
     const int tid = fresh_tid();
     const int lane = tid & 63;
@@ -553,18 +604,37 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
     const int l1 = lane >> 3, l0 = lane & 7;      // lane digits (y-ish, x-ish)
     const cf* tw = reinterpret_cast<const cf*>(lds + L::TW_OFF);
     const float* zre = reinterpret_cast<const float*>(lds + L::R_OFF);
-    const float* zim = zre + 64 * L::ZS;
+    const float* zim = zre + G::ROWS * G::ZS;
     float* xch = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::XCH_WAVE_BYTES);
 
     cf v[8][8];
 
     // ---- forward round A: lane = (y0, x0), registers = (y1, x1); y = y0 + 8 y1
+    // FOLD: the class's radix-2 fold of the samples beyond index 63 (they exist for
+    // y, x < 24 only: the cutout ends before 88)
+    const float fsx = cx ? -1.0f : 1.0f, fsy = cy ? -1.0f : 1.0f;
 #pragma unroll
     for (int y1 = 0; y1 < 8; ++y1)
 #pragma unroll
         for (int x1 = 0; x1 < 8; ++x1) {
-            const int a = (l1 + 8 * y1) * L::ZS + l0 + 8 * x1;
-            v[y1][x1] = cf{zre[a], bal * zim[a]};
+            const int a = (l1 + 8 * y1) * G::ZS + l0 + 8 * x1;
+            float re = zre[a], im = zim[a];
+            if constexpr (FOLD) {
+                if (x1 < 3) {
+                    re = __builtin_fmaf(fsx, zre[a + 64], re);
+                    im = __builtin_fmaf(fsx, zim[a + 64], im);
+                }
+                if (y1 < 3) {
+                    float re2 = zre[a + 64 * G::ZS], im2 = zim[a + 64 * G::ZS];
+                    if (x1 < 3) {
+                        re2 = __builtin_fmaf(fsx, zre[a + 64 * G::ZS + 64], re2);
+                        im2 = __builtin_fmaf(fsx, zim[a + 64 * G::ZS + 64], im2);
+                    }
+                    re = __builtin_fmaf(fsy, re2, re);
+                    im = __builtin_fmaf(fsy, im2, im);
+                }
+            }
+            v[y1][x1] = cf{re, bal * im};
         }
     rt::block_sync_lds();                       // all waves have read the staged input
     clk.tick(1);
@@ -709,43 +779,44 @@ SPX_DEVICE float window_value(const unsigned char* lds, int ny, int nx, int qy, 
 // ---------------------------------------------------------------------------
 // statistics for cc.py:131-156 over `npool` images (1: pair mode, 4: 5-image)
 // ---------------------------------------------------------------------------
-SPX_DEVICE NormStats norm_stats(unsigned char* lds_scr, const float* __restrict__ ref,
-                                const float* __restrict__ ims, int npool, int64_t im_stride,
-                                int ny, int nx, int cc_type) {
-    NormStats ns;
+template <typename TIn>
+SPX_DEVICE NormStatsT<TIn> norm_stats(unsigned char* lds_scr, const TIn* __restrict__ ref,
+                                      const TIn* __restrict__ ims, int npool, int64_t im_stride,
+                                      int ny, int nx, int cc_type) {
+    NormStatsT<TIn> ns;
     ns.active = 0;
-    ns.im_mean = 0.0f; ns.im_std = 1.0f; ns.ref_mean = 0.0f; ns.ref_std = 1.0f;
+    ns.im_mean = 0; ns.im_std = 1; ns.ref_mean = 0; ns.ref_std = 1;
     if (cc_type == CC_PLAIN) return ns;
     const int tid = fresh_tid();
     const int npx = ny * nx;
-    // 16-byte loads when the layout allows it (images are im_stride apart, each npx floats)
+    // 16-byte loads when the layout allows it (images are im_stride apart, each npx pixels)
     bool vec = (npx & 3) == 0 && (im_stride & 3) == 0 &&
                ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(ims)) & 15) == 0;
-    const int nchunk = vec ? npx >> 2 : npx;        // loop units: float4 or float
+    const int nchunk = vec ? npx >> 2 : npx;        // loop units: 4 pixels or 1
     // ONE pass: counts, sums and sums of squares in float64 (pooled image pixels != 0; ref over
     // the union mask).  numpy's std is the population form (ddof = 0) about the mean; in
     // float64, sum(x^2)/n - mean^2 agrees with it to ~1e-16 * mean^2/var, far below float32.
     double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // n_im, sum_im, sum_im^2, n_union, sum_ref, sum_ref^2
 #pragma unroll 2
     for (int i = tid; i < nchunk; i += kThreads) {
-        f32x4 r4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        Quad<TIn> r4 = Quad<TIn>{{0, 0, 0, 0}};
         unsigned anym = 0;
-        if (vec) r4 = reinterpret_cast<const f32x4*>(ref)[i]; else r4[0] = ref[i];
+        if (vec) r4 = load_quad(ref + 4 * (int64_t)i); else r4.v[0] = ref[i];
         for (int q = 0; q < npool; ++q) {
-            f32x4 m4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (vec) m4 = reinterpret_cast<const f32x4*>(ims + q * im_stride)[i];
-            else m4[0] = ims[q * im_stride + i];
+            Quad<TIn> m4 = Quad<TIn>{{0, 0, 0, 0}};
+            if (vec) m4 = load_quad(ims + q * im_stride + 4 * (int64_t)i);
+            else m4.v[0] = ims[q * im_stride + i];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (m4[e] != 0.0f) {
-                    const double x = (double)m4[e];
+                if (m4.v[e] != (TIn)0) {
+                    const double x = (double)m4.v[e];
                     a[0] += 1.0; a[1] += x; a[2] += x * x; anym |= 1u << e;
                 }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (anym & (1u << e)) {
-                const double x = (double)r4[e];
+                const double x = (double)r4.v[e];
                 a[3] += 1.0; a[4] += x; a[5] += x * x;
             }
     }
@@ -759,10 +830,10 @@ SPX_DEVICE NormStats norm_stats(unsigned char* lds_scr, const float* __restrict_
     if (b[1] < 0.0) b[1] = 0.0;
     ns.active = 1;
     const bool zero = (cc_type == CC_ZNCC);
-    ns.im_mean = zero ? (float)im_mean : 0.0f;
-    ns.im_std = (float)sqrt(b[0] / n_im);
-    ns.ref_mean = zero ? (float)ref_mean : 0.0f;
-    ns.ref_std = (float)sqrt(b[1] / n_un);
+    ns.im_mean = zero ? (TIn)im_mean : (TIn)0;
+    ns.im_std = (TIn)sqrt(b[0] / n_im);
+    ns.ref_mean = zero ? (TIn)ref_mean : (TIn)0;
+    ns.ref_std = (TIn)sqrt(b[1] / n_un);
     return ns;
 }
 
@@ -967,10 +1038,57 @@ SPX_DEVICE float fine_value(const unsigned char* lds, int b, int a) {
 // index l = m or m + 64, whichever lies in the window [lo, lo + n), lo = (n-1)/2;
 // its flipped window index is q = (n-1) + lo - l (see conv_index).
 // ---------------------------------------------------------------------------
+// FOLD (cutouts of 65..85 px): the window [lo, lo + n) is longer than a plane, so a plane
+// element stands for up to two convolution indices per axis, m (sign +) and m + 64 (sign of
+// the odd classes flipped); all four combinations are formed from the same four loads.
 template <int C>
+SPX_DEVICE void coarse_argmax_fold(const unsigned char* lds, int ny, int nx, float& bv, int& bi) {
+    typedef Lds<C> L;
+    static_assert(C == 2, "");
+    const int tid = fresh_tid();
+    const int loy = (ny - 1) / 2, lox = (nx - 1) / 2;
+    const int mx4 = (tid & 15) << 2;
+    // flipped window index of candidate A (l = m) and B (l = m + 64); negative = outside
+    int qxa[4], qxb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int mx = mx4 + e;
+        qxa[e] = mx >= lox ? (nx - 1) + lox - mx : -1;
+        qxb[e] = (nx - 1) + lox - mx - 64;
+    }
+    float m = -__builtin_inff();
+    int best = kNoIndex;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int my = (tid >> 4) + 16 * i;
+        const int qya = my >= loy ? (ny - 1) + loy - my : -1;
+        const int qyb = (ny - 1) + loy - my - 64;
+        f32x4 d[C * C];
+#pragma unroll
+        for (int c = 0; c < C * C; ++c)
+            d[c] = *reinterpret_cast<const f32x4*>(lds + L::R_OFF + c * L::PLANE_STRIDE_BYTES +
+                                                   (my * L::PS + plane_col(my, mx4)) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // same association as window_value: (d00 + fx d01) + fy (d10 + fx d11)
+            const float up = d[0][e] + d[1][e], um = d[0][e] - d[1][e];
+            const float tp = d[2][e] + d[3][e], tm = d[2][e] - d[3][e];
+            const float vaa = up + tp, vab = um + tm, vba = up - tp, vbb = um - tm;   // [y][x]
+            if (qya >= 0 && qxa[e] >= 0 && better(vaa, qya * nx + qxa[e], m, best)) { m = vaa; best = qya * nx + qxa[e]; }
+            if (qya >= 0 && qxb[e] >= 0 && better(vab, qya * nx + qxb[e], m, best)) { m = vab; best = qya * nx + qxb[e]; }
+            if (qyb >= 0 && qxa[e] >= 0 && better(vba, qyb * nx + qxa[e], m, best)) { m = vba; best = qyb * nx + qxa[e]; }
+            if (qyb >= 0 && qxb[e] >= 0 && better(vbb, qyb * nx + qxb[e], m, best)) { m = vbb; best = qyb * nx + qxb[e]; }
+        }
+    }
+    bv = m;
+    bi = best;
+}
+
+template <int C, bool FOLD = false>
 SPX_DEVICE void coarse_argmax(const unsigned char* lds, int ny, int nx, float& bv, int& bi) {
     typedef Lds<C> L;
     static_assert(C == 2, "");
+    if constexpr (FOLD) { coarse_argmax_fold<C>(lds, ny, nx, bv, bi); return; }
     const int tid = fresh_tid();
     const int loy = (ny - 1) / 2, lox = (nx - 1) / 2;
     const float ninf = -__builtin_inff();
@@ -1049,12 +1167,12 @@ SPX_DEVICE PeakResult peak_fit_wave0(unsigned char* lds_scr, int imax, int jmax,
 // Pair kernel: one workgroup per (ref, img) pair.
 //   out[2*pair + {0,1}] = (dx, dy) float64, status[pair]
 // ---------------------------------------------------------------------------
-template <int C, int WB, int DBG = 0>
-SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict__ img,
+template <int C, int WB, int DBG = 0, bool FOLD = false, typename TIn = float>
+SPX_DEVICE void pair_body(const TIn* __restrict__ ref, const TIn* __restrict__ img,
                           int ny, int nx, int U, int cc_type, const cf* __restrict__ tw_g,
                           const float* __restrict__ ktab, double* __restrict__ out,
                           int* __restrict__ status, unsigned char* lds, PhaseClock<DBG>& clk,
-                          const float* __restrict__ next_ref, const float* __restrict__ next_img,
+                          const TIn* __restrict__ next_ref, const TIn* __restrict__ next_img,
                           float& warm, int fit_wave, double inv_u) {
     typedef Lds<C> L;
     ny = rt::launder_uniform(ny);
@@ -1062,19 +1180,19 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
     U = rt::launder_uniform(U);
     const int tid = fresh_tid();
     unsigned char* scr = lds + L::SCR_OFF;
-    const NormStats ns = norm_stats(scr, ref, img, 1, 0, ny, nx, cc_type);
+    const NormStatsT<TIn> ns = norm_stats(scr, ref, img, 1, 0, ny, nx, cc_type);
     float ssq[2];
     rt::consume(warm);        // the warm-up load of this pair has landed (or was never issued)
-    stage_pair<C>(lds, ref, img, ny, nx, ns, ssq);
+    stage_pair<C, FOLD, TIn>(lds, ref, img, ny, nx, ns, ssq);
     const float bal = balance_factor(scr, ssq);       // includes the barrier after staging
     const float oscale = 0.5f / ((float)(L::P * L::P) * bal);
     clk.tick(0);
     if constexpr (DBG == 1) return;
     const int rot = (C * C - fit_wave) & (C * C - 1);     // the fitting wave takes the lightest class (0,0)
-    if (cc_planes<C, DBG>(lds, bal, clk, rot)) return;
+    if (cc_planes<C, DBG, FOLD>(lds, bal, clk, rot)) return;
     if constexpr (DBG == 10) return;
     // pull the next pair into L2 while this one is in its tail
-    if (next_ref) warm = warm_next_pair(next_ref, next_img);
+    if constexpr (sizeof(TIn) == 4) if (next_ref) warm = warm_next_pair(next_ref, next_img);
 
     // the refine stage's constant operands: issue the loads now, use them after the arg-max
     FineTables<(WB > 0 ? WB : 1)> ft;
@@ -1082,14 +1200,22 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
     // coarse arg-max over the flipped 'same' window (centroid.py:114-116)
     float bv;
     int bi;
-    coarse_argmax<C>(lds, ny, nx, bv, bi);
+    coarse_argmax<C, FOLD>(lds, ny, nx, bv, bi);
     block_argmax(scr, bv, bi, 0);
+    // A NaN or Inf pixel makes the whole correlation NaN and no element ever compares greater:
+    // numpy.argmax then returns index 0 and find_peak its integer position (centroid.py:114,
+    // 171-172); same result here, flagged ST_NONFINITE, and the refine stage is skipped
+    // (workgroup-uniform: every thread holds the same bi).
+    const bool nonfinite = bi == kNoIndex;
+    if (nonfinite) bi = 0;
     int qyc = bi / nx, qxc = bi - (bi / nx) * nx;
     clk.tick(11);
     if constexpr (DBG == 11) { if (tid == 0) out[0] = (double)bi; return; }
 
     PeakResult pk;
-    if constexpr (WB == 0) {
+    if (nonfinite) {
+        pk.x = 0.0; pk.y = 0.0; pk.status = ST_NONFINITE;
+    } else if constexpr (WB == 0) {
         pk = peak_fit_wave0(scr, qxc, qyc, nx, ny, [&](int x, int y) {
             return window_value<C>(lds, ny, nx, y, x, oscale);
         }, fit_wave);
@@ -1119,6 +1245,7 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
             wave_argmax(fv, fi);
             clk.tick(13);
             if constexpr (DBG == 13) { if (tid == 0) out[0] = (double)fi; return; }
+            if (fi == kNoIndex) { imax = jmax = -1; break; }     // non-finite window (overflow)
             const int a = fi / W, b = fi % W;
             jmax = fy0 + a;
             imax = fx0 + b;
@@ -1144,6 +1271,8 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
             pk = peak_fit_wave0(scr, imax, jmax, NX, NY, [&](int x, int y) {
                 return fine_value<C, W>(lds, x - fx0, y - fy0);
             }, fit_wave);
+        } else if (imax < 0) {
+            pk.x = 0.0; pk.y = 0.0; pk.status = ST_NONFINITE;
         } else {
             pk.x = (double)imax; pk.y = (double)jmax; pk.status = ST_WINDOW;
         }
@@ -1158,8 +1287,8 @@ SPX_DEVICE void pair_body(const float* __restrict__ ref, const float* __restrict
     clk.tick(14);
 }
 
-template <int C, int WB, int DBG = 0>
-SPX_TKERNEL(256) void pair_kernel(const float* __restrict__ ref, const float* __restrict__ img,
+template <int C, int WB, int DBG = 0, bool FOLD = false, typename TIn = float>
+SPX_TKERNEL(256) void pair_kernel(const TIn* __restrict__ ref, const TIn* __restrict__ img,
                                   int64_t nbatch, int ny, int nx, int U, int cc_type,
                                   const cf* __restrict__ tw_g, const float* __restrict__ ktab,
                                   double* __restrict__ out, int* __restrict__ status) {
@@ -1168,7 +1297,7 @@ SPX_TKERNEL(256) void pair_kernel(const float* __restrict__ ref, const float* __
     PhaseClock<DBG> clk;
     clk.start();
     const int64_t stride = (int64_t)ny * nx;
-    const bool full = ny == 64 && nx == 64 &&
+    const bool full = !FOLD && sizeof(TIn) == 4 && ny == 64 && nx == 64 &&
         ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(img)) & 15) == 0;
     const int64_t step = rt::grid_size();
     float warm = 0.0f;
@@ -1180,7 +1309,7 @@ SPX_TKERNEL(256) void pair_kernel(const float* __restrict__ ref, const float* __
     const double inv_u = rt::read_lane(1.0 / (double)U, 0);
     for (int64_t p = rt::block_id(); p < nbatch; p += step) {
         const bool more = full && (p + step < nbatch);
-        pair_body<C, WB, DBG>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, tw_g, ktab,
+        pair_body<C, WB, DBG, FOLD, TIn>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, tw_g, ktab,
                               out + 2 * p, status ? status + p : nullptr, lds, clk,
                               more ? ref + (p + step) * stride : nullptr,
                               more ? img + (p + step) * stride : nullptr, warm, fit_wave, inv_u);
@@ -1207,11 +1336,59 @@ SPX_TKERNEL(256) void pair_kernel(const float* __restrict__ ref, const float* __
 // (cc.py:121-126), walking the class planes in storage order exactly like coarse_argmax
 // (16-byte LDS reads, 3 FMAs per element); (bv, bi) accumulate the arg-max over the
 // interlaced image (index = row-major position in it).
+// FOLD variant (65..85 px), see coarse_argmax_fold
 template <int C>
+SPX_DEVICE void interlace_window_fold(const unsigned char* lds, int ny, int nx, float out_scale,
+                                      float* __restrict__ icc, int ox, int oy, float& bv, int& bi) {
+    typedef Lds<C> L;
+    static_assert(C == 2, "");
+    const int tid = fresh_tid();
+    const int loy = (ny - 1) / 2, lox = (nx - 1) / 2;
+    const int NX = 2 * nx;
+    const int mx4 = (tid & 15) << 2;
+    int gxa[4], gxb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int mx = mx4 + e;
+        const int qb = (nx - 1) + lox - mx - 64;
+        gxa[e] = mx >= lox ? 2 * ((nx - 1) + lox - mx) + ox : -1;
+        gxb[e] = qb >= 0 ? 2 * qb + ox : -1;
+    }
+    float m = bv;
+    int best = bi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int my = (tid >> 4) + 16 * i;
+        const int qb = (ny - 1) + loy - my - 64;
+        const int rowa = my >= loy ? (2 * ((ny - 1) + loy - my) + oy) * NX : -1;
+        const int rowb = qb >= 0 ? (2 * qb + oy) * NX : -1;
+        f32x4 d[C * C];
+#pragma unroll
+        for (int c = 0; c < C * C; ++c)
+            d[c] = *reinterpret_cast<const f32x4*>(lds + L::R_OFF + c * L::PLANE_STRIDE_BYTES +
+                                                   (my * L::PS + plane_col(my, mx4)) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float up = d[0][e] + d[1][e], um = d[0][e] - d[1][e];
+            const float tp = d[2][e] + d[3][e], tm = d[2][e] - d[3][e];
+            const float vaa = (up + tp) * out_scale, vab = (um + tm) * out_scale;
+            const float vba = (up - tp) * out_scale, vbb = (um - tm) * out_scale;
+            if (rowa >= 0 && gxa[e] >= 0) { icc[rowa + gxa[e]] = vaa; if (better(vaa, rowa + gxa[e], m, best)) { m = vaa; best = rowa + gxa[e]; } }
+            if (rowa >= 0 && gxb[e] >= 0) { icc[rowa + gxb[e]] = vab; if (better(vab, rowa + gxb[e], m, best)) { m = vab; best = rowa + gxb[e]; } }
+            if (rowb >= 0 && gxa[e] >= 0) { icc[rowb + gxa[e]] = vba; if (better(vba, rowb + gxa[e], m, best)) { m = vba; best = rowb + gxa[e]; } }
+            if (rowb >= 0 && gxb[e] >= 0) { icc[rowb + gxb[e]] = vbb; if (better(vbb, rowb + gxb[e], m, best)) { m = vbb; best = rowb + gxb[e]; } }
+        }
+    }
+    bv = m;
+    bi = best;
+}
+
+template <int C, bool FOLD = false>
 SPX_DEVICE void interlace_window(const unsigned char* lds, int ny, int nx, float out_scale,
                                  float* __restrict__ icc, int ox, int oy, float& bv, int& bi) {
     typedef Lds<C> L;
     static_assert(C == 2, "");
+    if constexpr (FOLD) { interlace_window_fold<C>(lds, ny, nx, out_scale, icc, ox, oy, bv, bi); return; }
     const int tid = fresh_tid();
     const int loy = (ny - 1) / 2, lox = (nx - 1) / 2;
     const int NX = 2 * nx;
@@ -1264,8 +1441,8 @@ SPX_DEVICE void interlace_window(const unsigned char* lds, int ny, int nx, float
     if (better(m, best, bv, bi)) { bv = m; bi = best; }
 }
 
-template <int C>
-SPX_DEVICE void disp5_body(const float* __restrict__ ref, const float* __restrict__ im4,
+template <int C, bool FOLD = false, typename TIn = float>
+SPX_DEVICE void disp5_body(const TIn* __restrict__ ref, const TIn* __restrict__ im4,
                            int ny, int nx, int cc_type, const cf* __restrict__ tw_g,
                            float* __restrict__ icc, double* __restrict__ out,
                            int* __restrict__ status, unsigned char* lds) {
@@ -1273,7 +1450,7 @@ SPX_DEVICE void disp5_body(const float* __restrict__ ref, const float* __restric
     const int tid = rt::thread_id();
     unsigned char* scr = lds + L::SCR_OFF;
     const int64_t stride = (int64_t)ny * nx;
-    const NormStats ns = norm_stats(scr, ref, im4, 4, stride, ny, nx, cc_type);
+    const NormStatsT<TIn> ns = norm_stats(scr, ref, im4, 4, stride, ny, nx, cc_type);
 
     float bv = -__builtin_inff();
     int bi = 0x7fffffff;
@@ -1281,20 +1458,23 @@ SPX_DEVICE void disp5_body(const float* __restrict__ ref, const float* __restric
     for (int q = 0; q < 4; ++q) {            // order 00, 10, 01, 11 (cc.py:114-117)
         const int ox = q & 1, oy = q >> 1;   // icc[oy::2, ox::2] = cc[::-1, ::-1]
         float ssq[2];
-        stage_pair<C>(lds, ref, im4 + q * stride, ny, nx, ns, ssq);
+        stage_pair<C, FOLD, TIn>(lds, ref, im4 + q * stride, ny, nx, ns, ssq);
         const float bal = balance_factor(scr, ssq);
         const float oscale = 0.5f / ((float)(L::P * L::P) * bal);
         PhaseClock<0> noclk;
-        cc_planes<C>(lds, bal, noclk);
-        interlace_window<C>(lds, ny, nx, oscale, icc, ox, oy, bv, bi);
+        cc_planes<C, 0, FOLD>(lds, bal, noclk);
+        interlace_window<C, FOLD>(lds, ny, nx, oscale, icc, ox, oy, bv, bi);
         rt::block_sync_lds();                    // planes are overwritten by the next stage
     }
     rt::block_sync();        // icc (GLOBAL memory) written above is read below by other waves
     block_argmax(scr, bv, bi, 0);
+    const bool nonfinite = bi == kNoIndex;      // NaN everywhere: numpy.argmax -> 0 (see pair_body)
+    if (nonfinite) bi = 0;
     const int jmax = bi / NX, imax = bi % NX;
     PeakResult pk = peak_from_argmax(scr, imax, jmax, NX, NY, [&](int x, int y) {
         return icc[y * NX + x];
     });
+    if (nonfinite) pk.status = ST_NONFINITE;
     if (tid == 0) {
         out[0] = 0.5 * pk.x - (double)((NX - 1) / 4);     // cc.py:89-93
         out[1] = 0.5 * pk.y - (double)((NY - 1) / 4);
@@ -1302,8 +1482,8 @@ SPX_DEVICE void disp5_body(const float* __restrict__ ref, const float* __restric
     }
 }
 
-template <int C>
-SPX_TKERNEL(256) void disp5_kernel(const float* __restrict__ ref, const float* __restrict__ im4,
+template <int C, bool FOLD = false, typename TIn = float>
+SPX_TKERNEL(256) void disp5_kernel(const TIn* __restrict__ ref, const TIn* __restrict__ im4,
                                    int64_t nbatch, int ny, int nx, int cc_type,
                                    const cf* __restrict__ tw_g, float* __restrict__ icc,
                                    double* __restrict__ out, int* __restrict__ status) {
@@ -1311,7 +1491,7 @@ SPX_TKERNEL(256) void disp5_kernel(const float* __restrict__ ref, const float* _
     load_twiddles<C>(lds, tw_g);
     const int64_t stride = (int64_t)ny * nx;
     for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
-        disp5_body<C>(ref + p * stride, im4 + 4 * p * stride, ny, nx, cc_type, tw_g,
+        disp5_body<C, FOLD, TIn>(ref + p * stride, im4 + 4 * p * stride, ny, nx, cc_type, tw_g,
                       icc + 4 * p * stride, out + 2 * p, status ? status + p : nullptr, lds);
         rt::block_sync_lds();
     }

@@ -43,7 +43,9 @@ template <int C> struct LdsBig {
     static SPX_DEVICE int wrap(int x) {
         x += x < 0 ? P : 0;
         x -= x >= P ? P : 0;
-        return x;
+        // callers stay inside [-P, 2P); anything else (a corrupted index) is folded into range
+        // instead of becoming an out-of-bounds address
+        return (unsigned)x < (unsigned)P ? x : 0;
     }
 };
 typedef LdsBig<4> Lds128;
@@ -53,9 +55,10 @@ constexpr size_t kWs96Bytes = LdsBig<3>::kWsBytes;
 struct __attribute__((packed, aligned(4))) F32x4U { float v[4]; };   // 16-byte load, 4-byte aligned
 
 // one 64x64 quadrant block (sy, sx) of z = ref + i*bal*flip(img), normalised, into LDS
-SPX_DEVICE void stage_block128(unsigned char* lds, const float* __restrict__ ref,
-                               const float* __restrict__ img, int ny, int nx, int sy, int sx,
-                               const NormStats& ns, float bal) {
+template <typename TIn>
+SPX_DEVICE void stage_block128(unsigned char* lds, const TIn* __restrict__ ref,
+                               const TIn* __restrict__ img, int ny, int nx, int sy, int sx,
+                               const NormStatsT<TIn>& ns, float bal) {
     typedef Lds128 L;
     const int tid = fresh_tid();
     float* zre = reinterpret_cast<float*>(lds + L::R_OFF);
@@ -70,23 +73,26 @@ SPX_DEVICE void stage_block128(unsigned char* lds, const float* __restrict__ ref
         const int y = yl + 64 * sy, x = 4 * x4 + 64 * sx;
         float rr[4] = {0.f, 0.f, 0.f, 0.f}, mm[4] = {0.f, 0.f, 0.f, 0.f};
         if (y < ny && x < nx) {
-            const float* rrow = ref + (int64_t)y * nx + x;
-            const float* mrow = img + (int64_t)(ny - 1 - y) * nx + (nx - 1 - x);     // pixel x, then x+1 at -1, ...
+            const TIn* rrow = ref + (int64_t)y * nx + x;
+            const TIn* mrow = img + (int64_t)(ny - 1 - y) * nx + (nx - 1 - x);     // pixel x, then x+1 at -1, ...
+            TIn ri[4] = {0, 0, 0, 0}, mi[4] = {0, 0, 0, 0};
             if (x + 3 < nx) {
-                const F32x4U r = *reinterpret_cast<const F32x4U*>(rrow);
-                const F32x4U t = *reinterpret_cast<const F32x4U*>(mrow - 3);
+                const Quad<TIn> r = load_quad(rrow);
+                const Quad<TIn> t = load_quad(mrow - 3);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { rr[e] = r.v[e]; mm[e] = t.v[3 - e]; }
+                for (int e = 0; e < 4; ++e) { ri[e] = r.v[e]; mi[e] = t.v[3 - e]; }
             } else {
-                for (int e = 0; e < 4 && x + e < nx; ++e) { rr[e] = rrow[e]; mm[e] = mrow[-e]; }
+                for (int e = 0; e < 4 && x + e < nx; ++e) { ri[e] = rrow[e]; mi[e] = mrow[-e]; }
             }
             const int nin = nx - x < 4 ? nx - x : 4;          // pixels of the chunk inside the cutout
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (ns.active && e < nin) {
-                    if (mm[e] != 0.0f) { mm[e] = mm[e] - ns.im_mean; mm[e] = mm[e] / ns.im_std; }
-                    rr[e] = rr[e] - ns.ref_mean;
-                    rr[e] = rr[e] / ns.ref_std;
+                    mm[e] = norm_im(mi[e], ns);
+                    rr[e] = norm_ref(ri[e], ns);
+                } else {
+                    mm[e] = (float)mi[e];
+                    rr[e] = (float)ri[e];
                 }
                 mm[e] *= bal;
             }
@@ -98,36 +104,39 @@ SPX_DEVICE void stage_block128(unsigned char* lds, const float* __restrict__ ref
 
 // sum ref^2 and sum img^2 over the cutout (after normalisation) -> balance factor.
 // Latency-bound (2 workgroups/CU): 16-byte loads, 16 of them in flight per thread.
-SPX_DEVICE float balance128(unsigned char* scr, const float* __restrict__ ref,
-                            const float* __restrict__ img, int ny, int nx, const NormStats& ns) {
+template <typename TIn>
+SPX_DEVICE float balance128(unsigned char* scr, const TIn* __restrict__ ref,
+                            const TIn* __restrict__ img, int ny, int nx, const NormStatsT<TIn>& ns) {
     const int tid = fresh_tid();
     float ssq[2] = {0.0f, 0.0f};
     const int npx = ny * nx;
     const bool vec = (npx & 3) == 0 &&
                      ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(img)) & 15) == 0;
-    auto add = [&](float r, float m) {
+    auto add = [&](TIn ri, TIn mi) {
+        float r = (float)ri, m = (float)mi;
         if (ns.active) {
-            if (m != 0.0f) m = (m - ns.im_mean) / ns.im_std;
-            r = (r - ns.ref_mean) / ns.ref_std;
+            m = norm_im(mi, ns);
+            r = norm_ref(ri, ns);
         }
         ssq[0] += r * r;
         ssq[1] += m * m;
     };
     if (vec) {
         const int n4 = npx >> 2;
-        for (int base = 0; base < n4; base += 8 * kThreads) {
-            f32x4 r[8], m[8];
+        constexpr int UN = sizeof(TIn) == 4 ? 8 : 4;      // 16 loads of 16 bytes in flight per thread
+        for (int base = 0; base < n4; base += UN * kThreads) {
+            Quad<TIn> r[UN], m[UN];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UN; ++u) {
                 const int i = base + u * kThreads + tid;
-                r[u] = i < n4 ? reinterpret_cast<const f32x4*>(ref)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-                m[u] = i < n4 ? reinterpret_cast<const f32x4*>(img)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                r[u] = i < n4 ? load_quad(ref + 4 * (int64_t)i) : Quad<TIn>{{0, 0, 0, 0}};
+                m[u] = i < n4 ? load_quad(img + 4 * (int64_t)i) : Quad<TIn>{{0, 0, 0, 0}};
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < UN; ++u)
                 if (base + u * kThreads + tid < n4) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) add(r[u][e], m[u][e]);
+                    for (int e = 0; e < 4; ++e) add(r[u].v[e], m[u].v[e]);
                 }
         }
     } else {
@@ -138,9 +147,9 @@ SPX_DEVICE float balance128(unsigned char* scr, const float* __restrict__ ref,
 }
 
 // One round: classes (cy, cx = wave) of the staged pair -> complex planes in the workspace.
-template <int C, int DBG>
-SPX_DEVICE void class_round128(unsigned char* lds, const float* __restrict__ ref,
-                               const float* __restrict__ img, int ny, int nx, const NormStats& ns,
+template <int C, int DBG, typename TIn>
+SPX_DEVICE void class_round128(unsigned char* lds, const TIn* __restrict__ ref,
+                               const TIn* __restrict__ img, int ny, int nx, const NormStatsT<TIn>& ns,
                                float bal, int cy, float* __restrict__ ws, PhaseClock<DBG>& clk) {
     typedef LdsBig<C> L;
     static_assert(C == 3 || C == 4, "");
@@ -354,15 +363,15 @@ SPX_DEVICE void combine128(const float* __restrict__ ws, float* __restrict__ con
 }
 
 // cutout pair -> full PxP convolution in the workspace (ends with a full barrier)
-template <int C, int DBG>
-SPX_DEVICE void conv_full128(unsigned char* lds, const float* __restrict__ ref,
-                             const float* __restrict__ img, int ny, int nx, const NormStats& ns,
+template <int C, int DBG, typename TIn>
+SPX_DEVICE void conv_full128(unsigned char* lds, const TIn* __restrict__ ref,
+                             const TIn* __restrict__ img, int ny, int nx, const NormStatsT<TIn>& ns,
                              float* __restrict__ ws, PhaseClock<DBG>& clk) {
     typedef LdsBig<C> L;
     unsigned char* scr = lds + L::SCR_OFF;
     const float bal = balance128(scr, ref, img, ny, nx, ns);
     clk.tick(0);
-    for (int cy = 0; cy < C; ++cy) class_round128<C, DBG>(lds, ref, img, ny, nx, ns, bal, cy, ws, clk);
+    for (int cy = 0; cy < C; ++cy) class_round128<C, DBG, TIn>(lds, ref, img, ny, nx, ns, bal, cy, ws, clk);
     rt::block_sync();                    // class planes (global) visible to every wave
     // conv = Im(IFFT(Z^2)) / 2, IFFT normalisation 1/P^2, balance undone
     const float out_scale = 0.5f / ((float)(L::P) * (float)(L::P) * bal);
@@ -497,8 +506,8 @@ template <int W> SPX_DEVICE float fine_value128(const unsigned char* lds, int b,
 // ---------------------------------------------------------------------------
 // pair mode, 128 tile
 // ---------------------------------------------------------------------------
-template <int C, int WB, int DBG>
-SPX_DEVICE void pair128_body(const float* __restrict__ ref, const float* __restrict__ img, int ny,
+template <int C, int WB, int DBG, typename TIn>
+SPX_DEVICE void pair128_body(const TIn* __restrict__ ref, const TIn* __restrict__ img, int ny,
                              int nx, int U, int cc_type, const float* __restrict__ ktab,
                              double* __restrict__ out, int* __restrict__ status,
                              unsigned char* lds, float* __restrict__ ws, PhaseClock<DBG>& clk) {
@@ -508,18 +517,22 @@ SPX_DEVICE void pair128_body(const float* __restrict__ ref, const float* __restr
     U = rt::launder_uniform(U);
     const int tid = fresh_tid();
     unsigned char* scr = lds + L::SCR_OFF;
-    const NormStats ns = norm_stats(scr, ref, img, 1, 0, ny, nx, cc_type);
-    conv_full128<C, DBG>(lds, ref, img, ny, nx, ns, ws, clk);
+    const NormStatsT<TIn> ns = norm_stats(scr, ref, img, 1, 0, ny, nx, cc_type);
+    conv_full128<C, DBG, TIn>(lds, ref, img, ny, nx, ns, ws, clk);
     const float* conv = ws + L::kConvOffsetFloats;
 
     float bv;
     int bi;
     coarse_argmax128<C>(conv, ny, nx, bv, bi);
     block_argmax(scr, bv, bi, 0);
+    const bool nonfinite = bi == kNoIndex;       // NaN everywhere (see pair_body in spx_kernels.h)
+    if (nonfinite) bi = 0;
     int qyc = bi / nx, qxc = bi - (bi / nx) * nx;
     clk.tick(5);
     PeakResult pk;
-    if constexpr (WB == 0) {
+    if (nonfinite) {
+        pk.x = 0.0; pk.y = 0.0; pk.status = ST_NONFINITE;
+    } else if constexpr (WB == 0) {
         pk = peak_fit_wave0(scr, qxc, qyc, nx, ny, [&](int x, int y) {
             return window_value128<C>(conv, ny, nx, y, x);
         });
@@ -544,6 +557,7 @@ SPX_DEVICE void pair128_body(const float* __restrict__ ref, const float* __restr
             }
             block_argmax(scr, fv, fi, 1);
             clk.tick(7);
+            if (fi == kNoIndex) { imax = jmax = -1; break; }      // non-finite window (overflow)
             const int a = fi / W, b = fi % W;
             jmax = fy0 + a;
             imax = fx0 + b;
@@ -566,6 +580,8 @@ SPX_DEVICE void pair128_body(const float* __restrict__ ref, const float* __restr
             pk = peak_fit_wave0(scr, imax, jmax, NX, NY, [&](int x, int y) {
                 return fine_value128<W>(lds, x - fx0, y - fy0);
             });
+        } else if (imax < 0) {
+            pk.x = 0.0; pk.y = 0.0; pk.status = ST_NONFINITE;
         } else {
             pk.x = (double)imax; pk.y = (double)jmax; pk.status = ST_WINDOW;
         }
@@ -584,8 +600,8 @@ template <int C> SPX_DEVICE void load_twiddles128(unsigned char* lds, const cf* 
     rt::block_sync_lds();
 }
 
-template <int C, int WB, int DBG = 0>
-SPX_TKERNEL(256) void pair128_kernel(const float* __restrict__ ref, const float* __restrict__ img,
+template <int C, int WB, int DBG = 0, typename TIn = float>
+SPX_TKERNEL(256) void pair128_kernel(const TIn* __restrict__ ref, const TIn* __restrict__ img,
                                      int64_t nbatch, int ny, int nx, int U, int cc_type,
                                      const cf* __restrict__ tw_g, const float* __restrict__ ktab,
                                      double* __restrict__ out, int* __restrict__ status,
@@ -597,7 +613,7 @@ SPX_TKERNEL(256) void pair128_kernel(const float* __restrict__ ref, const float*
     PhaseClock<DBG> clk;
     clk.start();
     for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
-        pair128_body<C, WB, DBG>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, ktab, out + 2 * p,
+        pair128_body<C, WB, DBG, TIn>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, ktab, out + 2 * p,
                               status ? status + p : nullptr, lds, ws, clk);
         rt::block_sync();
         clk.tick(9);
@@ -610,8 +626,8 @@ SPX_TKERNEL(256) void pair128_kernel(const float* __restrict__ ref, const float*
 // ---------------------------------------------------------------------------
 // reference (5-image) mode, 96 / 128 tile
 // ---------------------------------------------------------------------------
-template <int C>
-SPX_TKERNEL(256) void disp5_128_kernel(const float* __restrict__ ref, const float* __restrict__ im4,
+template <int C, typename TIn = float>
+SPX_TKERNEL(256) void disp5_128_kernel(const TIn* __restrict__ ref, const TIn* __restrict__ im4,
                                        int64_t nbatch, int ny, int nx, int cc_type,
                                        const cf* __restrict__ tw_g, float* __restrict__ icc_all,
                                        double* __restrict__ out_all, int* __restrict__ status,
@@ -625,17 +641,17 @@ SPX_TKERNEL(256) void disp5_128_kernel(const float* __restrict__ ref, const floa
     const int64_t stride = (int64_t)ny * nx;
     const int NX = 2 * nx, NY = 2 * ny;
     for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
-        const float* r = ref + p * stride;
-        const float* m4 = im4 + 4 * p * stride;
+        const TIn* r = ref + p * stride;
+        const TIn* m4 = im4 + 4 * p * stride;
         float* icc = icc_all + 4 * p * stride;
         const int tid = fresh_tid();
-        const NormStats ns = norm_stats(scr, r, m4, 4, stride, ny, nx, cc_type);
+        const NormStatsT<TIn> ns = norm_stats(scr, r, m4, 4, stride, ny, nx, cc_type);
         float bv = -__builtin_inff();
         int bi = 0x7fffffff;
         PhaseClock<0> clk;
         for (int q = 0; q < 4; ++q) {
             const int ox = q & 1, oy = q >> 1;
-            conv_full128<C, 0>(lds, r, m4 + q * stride, ny, nx, ns, ws, clk);
+            conv_full128<C, 0, TIn>(lds, r, m4 + q * stride, ny, nx, ns, ws, clk);
             const int qx = tid & 127;
             if (qx < nx) {
                 for (int qy = tid >> 7; qy < ny; qy += kThreads / 128) {
@@ -648,10 +664,13 @@ SPX_TKERNEL(256) void disp5_128_kernel(const float* __restrict__ ref, const floa
             rt::block_sync();
         }
         block_argmax(scr, bv, bi, 0);
+        const bool nonfinite = bi == kNoIndex;
+        if (nonfinite) bi = 0;
         const int jmax = bi / NX, imax = bi % NX;
         PeakResult pk = peak_fit_wave0(scr, imax, jmax, NX, NY, [&](int x, int y) {
             return icc[(size_t)y * NX + x];
         });
+        if (nonfinite) pk.status = ST_NONFINITE;
         if (tid == 0) {
             out_all[2 * p] = 0.5 * pk.x - (double)((NX - 1) / 4);
             out_all[2 * p + 1] = 0.5 * pk.y - (double)((NY - 1) / 4);

@@ -59,19 +59,20 @@ template <int DIR> SPX_DEVICE void fft4_classes(cf (&v)[8][8]) {
 }
 
 // cc.py:131-156 statistics for one wave's pair (npool images), wave-level reductions
-SPX_DEVICE NormStats norm_stats_wave(const float* __restrict__ ref, const float* __restrict__ ims,
+template <typename TIn>
+SPX_DEVICE NormStatsT<TIn> norm_stats_wave(const TIn* __restrict__ ref, const TIn* __restrict__ ims,
                                      int npool, int64_t im_stride, int npx, int cc_type) {
-    NormStats ns;
+    NormStatsT<TIn> ns;
     ns.active = 0;
-    ns.im_mean = 0.0f; ns.im_std = 1.0f; ns.ref_mean = 0.0f; ns.ref_std = 1.0f;
+    ns.im_mean = 0; ns.im_std = 1; ns.ref_mean = 0; ns.ref_std = 1;
     if (cc_type == CC_PLAIN) return ns;
     const int lane = fresh_tid() & 63;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     for (int i = lane; i < npx; i += 64) {
         bool any = false;
         for (int q = 0; q < npool; ++q) {
-            const float m = ims[q * im_stride + i];
-            if (m != 0.0f) { a0 += 1.0; a1 += (double)m; any = true; }
+            const TIn m = ims[q * im_stride + i];
+            if (m != (TIn)0) { a0 += 1.0; a1 += (double)m; any = true; }
         }
         if (any) { a2 += 1.0; a3 += (double)ref[i]; }
     }
@@ -81,25 +82,26 @@ SPX_DEVICE NormStats norm_stats_wave(const float* __restrict__ ref, const float*
     for (int i = lane; i < npx; i += 64) {
         bool any = false;
         for (int q = 0; q < npool; ++q) {
-            const float m = ims[q * im_stride + i];
-            if (m != 0.0f) { const double d = (double)m - im_mean; b0 += d * d; any = true; }
+            const TIn m = ims[q * im_stride + i];
+            if (m != (TIn)0) { const double d = (double)m - im_mean; b0 += d * d; any = true; }
         }
         if (any) { const double d = (double)ref[i] - ref_mean; b1 += d * d; }
     }
     b0 = wave_sum(b0); b1 = wave_sum(b1);
     ns.active = 1;
     const bool zero = (cc_type == CC_ZNCC);
-    ns.im_mean = zero ? (float)im_mean : 0.0f;
-    ns.im_std = (float)sqrt(b0 / a0);
-    ns.ref_mean = zero ? (float)ref_mean : 0.0f;
-    ns.ref_std = (float)sqrt(b1 / a2);
+    ns.im_mean = zero ? (TIn)im_mean : (TIn)0;
+    ns.im_std = (TIn)sqrt(b0 / a0);
+    ns.ref_mean = zero ? (TIn)ref_mean : (TIn)0;
+    ns.ref_std = (TIn)sqrt(b1 / a2);
     return ns;
 }
 
 // (ref, flipped img) of one pair -> the four real class planes in the wave's buffer `wbuf`.
 // Returns the exact power-of-two balance factor applied to the image.
-SPX_DEVICE float cc_planes32(const cf* tw, float* wbuf, const float* __restrict__ ref,
-                             const float* __restrict__ img, int ny, int nx, const NormStats& ns) {
+template <typename TIn>
+SPX_DEVICE float cc_planes32(const cf* tw, float* wbuf, const TIn* __restrict__ ref,
+                             const TIn* __restrict__ img, int ny, int nx, const NormStatsT<TIn>& ns) {
     typedef Lds32 L;
     const int lane = fresh_tid() & 63;
     const int cls = lane >> 4, cy = cls >> 1, cx = cls & 1;       // round-A lane = (class, y0, x0)
@@ -114,12 +116,13 @@ SPX_DEVICE float cc_planes32(const cf* tw, float* wbuf, const float* __restrict_
         const int y = idx >> 5, x = idx & 31;
         float r = 0.0f, m = 0.0f;
         if (y < ny && x < nx) {
-            r = ref[y * nx + x];
-            m = img[(ny - 1 - y) * nx + (nx - 1 - x)];               // flipped: cc.py:114
+            const TIn ri = ref[y * nx + x];
+            const TIn mi = img[(ny - 1 - y) * nx + (nx - 1 - x)];    // flipped: cc.py:114
+            r = (float)ri;
+            m = (float)mi;
             if (ns.active) {
-                if (m != 0.0f) { m = m - ns.im_mean; m = m / ns.im_std; }
-                r = r - ns.ref_mean;
-                r = r / ns.ref_std;
+                m = norm_im(mi, ns);
+                r = norm_ref(ri, ns);
             }
         }
         zre[y * L::ZS + x] = r;
@@ -129,12 +132,7 @@ SPX_DEVICE float cc_planes32(const cf* tw, float* wbuf, const float* __restrict_
     }
     sr = wave_sum_f(sr);
     sm = wave_sum_f(sm);
-    float bal = 1.0f;
-    if (sr > 0.0f && sm > 0.0f) {
-        const float ratio = __builtin_sqrtf(sr / sm);
-        if (ratio > 1e-30f && ratio < 1e30f)
-            bal = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, ratio) & 0x7f800000u);
-    }
+    const float bal = balance_from_ssq(sr, sm);
     rt::wave_sync();
 
     // ---- forward round A: x = x0 + 4 x1
@@ -360,24 +358,28 @@ SPX_DEVICE PeakResult peak_fit_wave(double* fit, int imax, int jmax, int NX, int
     return quad_fit_wave(v, lane, x1, y1, imax, jmax, NX, NY);
 }
 
-template <int WB>
-SPX_DEVICE void pair32_wave(const cf* tw, float* wbuf, double* fit, const float* __restrict__ ref,
-                            const float* __restrict__ img, int ny, int nx, int U, int cc_type,
+template <int WB, typename TIn>
+SPX_DEVICE void pair32_wave(const cf* tw, float* wbuf, double* fit, const TIn* __restrict__ ref,
+                            const TIn* __restrict__ img, int ny, int nx, int U, int cc_type,
                             const float* __restrict__ ktab, double* __restrict__ out,
                             int* __restrict__ status) {
     ny = rt::launder_uniform(ny);
     nx = rt::launder_uniform(nx);
     U = rt::launder_uniform(U);
     const int lane = fresh_tid() & 63;
-    const NormStats ns = norm_stats_wave(ref, img, 1, 0, ny * nx, cc_type);
+    const NormStatsT<TIn> ns = norm_stats_wave(ref, img, 1, 0, ny * nx, cc_type);
     const float bal = cc_planes32(tw, wbuf, ref, img, ny, nx, ns);
     const float oscale = 1.0f / ((float)(Lds32::P * Lds32::P) * bal);
     float bv;
     int bi;
     coarse_argmax32(wbuf, ny, nx, oscale, bv, bi);
+    const bool nonfinite = bi == kNoIndex;       // NaN everywhere (see pair_body in spx_kernels.h)
+    if (nonfinite) bi = 0;
     int qyc = bi / nx, qxc = bi - (bi / nx) * nx;
     PeakResult pk;
-    if constexpr (WB == 0) {
+    if (nonfinite) {
+        pk.x = 0.0; pk.y = 0.0; pk.status = ST_NONFINITE;
+    } else if constexpr (WB == 0) {
         pk = peak_fit_wave(fit, qxc, qyc, nx, ny, [&](int x, int y) {
             return window_value32(wbuf, ny, nx, y, x, oscale);
         });
@@ -401,6 +403,7 @@ SPX_DEVICE void pair32_wave(const cf* tw, float* wbuf, double* fit, const float*
                 }
             }
             wave_argmax(fv, fi);
+            if (fi == kNoIndex) { imax = jmax = -1; break; }      // non-finite window (overflow)
             const int a = fi / W, b = fi % W;
             jmax = fy0 + a;
             imax = fx0 + b;
@@ -423,6 +426,8 @@ SPX_DEVICE void pair32_wave(const cf* tw, float* wbuf, double* fit, const float*
             pk = peak_fit_wave(fit, imax, jmax, NX, NY, [&](int x, int y) {
                 return fbuf[(x - fx0) * W + (y - fy0)];
             });
+        } else if (imax < 0) {
+            pk.x = 0.0; pk.y = 0.0; pk.status = ST_NONFINITE;
         } else {
             pk.x = (double)imax; pk.y = (double)jmax; pk.status = ST_WINDOW;
         }
@@ -441,8 +446,8 @@ SPX_DEVICE void load_twiddles32(unsigned char* lds, const cf* __restrict__ tw_g)
     rt::block_sync_lds();
 }
 
-template <int WB>
-SPX_TKERNEL(256) void pair32_kernel(const float* __restrict__ ref, const float* __restrict__ img,
+template <int WB, typename TIn = float>
+SPX_TKERNEL(256) void pair32_kernel(const TIn* __restrict__ ref, const TIn* __restrict__ img,
                                     int64_t nbatch, int ny, int nx, int U, int cc_type,
                                     const cf* __restrict__ tw_g, const float* __restrict__ ktab,
                                     double* __restrict__ out, int* __restrict__ status) {
@@ -456,12 +461,13 @@ SPX_TKERNEL(256) void pair32_kernel(const float* __restrict__ ref, const float* 
     const int64_t stride = (int64_t)ny * nx;
     // one pair per wave; waves of a workgroup never synchronise with each other
     for (int64_t p = rt::block_id() * 4 + wave; p < nbatch; p += rt::grid_size() * 4)
-        pair32_wave<WB>(tw, wbuf, fit, ref + p * stride, img + p * stride, ny, nx, U, cc_type, ktab,
+        pair32_wave<WB, TIn>(tw, wbuf, fit, ref + p * stride, img + p * stride, ny, nx, U, cc_type, ktab,
                         out + 2 * p, status ? status + p : nullptr);
 }
 
 // reference (5-image) mode on the 32 tile: one wave per source
-SPX_TKERNEL(256) void disp5_32_kernel(const float* __restrict__ ref, const float* __restrict__ im4,
+template <typename TIn = float>
+SPX_TKERNEL(256) void disp5_32_kernel(const TIn* __restrict__ ref, const TIn* __restrict__ im4,
                                       int64_t nbatch, int ny, int nx, int cc_type,
                                       const cf* __restrict__ tw_g, float* __restrict__ icc_all,
                                       double* __restrict__ out_all, int* __restrict__ status) {
@@ -476,10 +482,10 @@ SPX_TKERNEL(256) void disp5_32_kernel(const float* __restrict__ ref, const float
     const int NX = 2 * nx, NY = 2 * ny;
     for (int64_t p = rt::block_id() * 4 + wave; p < nbatch; p += rt::grid_size() * 4) {
         const int lane = fresh_tid() & 63;
-        const float* r = ref + p * stride;
-        const float* m4 = im4 + 4 * p * stride;
+        const TIn* r = ref + p * stride;
+        const TIn* m4 = im4 + 4 * p * stride;
         float* icc = icc_all + 4 * p * stride;
-        const NormStats ns = norm_stats_wave(r, m4, 4, stride, ny * nx, cc_type);
+        const NormStatsT<TIn> ns = norm_stats_wave(r, m4, 4, stride, ny * nx, cc_type);
         float bv = -__builtin_inff();
         int bi = 0x7fffffff;
         for (int q = 0; q < 4; ++q) {
@@ -496,10 +502,13 @@ SPX_TKERNEL(256) void disp5_32_kernel(const float* __restrict__ ref, const float
             rt::wave_sync_mem();     // icc (global) is read back by other lanes for the fit
         }
         wave_argmax(bv, bi);
+        const bool nonfinite = bi == kNoIndex;
+        if (nonfinite) bi = 0;
         const int jmax = bi / NX, imax = bi % NX;
         PeakResult pk = peak_fit_wave(fit, imax, jmax, NX, NY, [&](int x, int y) {
             return icc[(size_t)y * NX + x];
         });
+        if (nonfinite) pk.status = ST_NONFINITE;
         if (lane == 0) {
             out_all[2 * p] = 0.5 * pk.x - (double)((NX - 1) / 4);
             out_all[2 * p + 1] = 0.5 * pk.y - (double)((NY - 1) / 4);

@@ -28,6 +28,20 @@ def init(device=None):
     return device
 
 
+def prepare(upsample=1):
+    """Build the constant tables of ``upsample`` for every kernel family on the current device and
+    raise the kernels' LDS limits (``spx_prepare``): afterwards launches neither allocate nor set
+    function attributes, so they can be captured into a HIP graph."""
+    init()
+    _ffi.check(_ffi.load().spx_prepare(int(upsample)))
+
+
+def shutdown():
+    """Free the library's device tables (``spx_shutdown``); the next call rebuilds them."""
+    _ffi.check(_ffi.load().spx_shutdown())
+    _initialised.clear()
+
+
 def to_device(a, dtype):
     """numpy array or torch tensor -> contiguous CUDA tensor of `dtype`."""
     dev = init()

@@ -1,27 +1,44 @@
 // TEST INFRASTRUCTURE ONLY: runs the kernels of subpixal_amd/csrc/spx_kernels.h on
 // CPU threads (spx_rt_emu.h) so tests can check their logic without a GPU.
+// The harness is compiled as four objects (EMU_PART 1..4: pair mode float32, pair mode float64,
+// reference mode, auxiliary kernels) so that `make -j` builds them side by side.
+#ifndef EMU_PART
+#error "compile with -DEMU_PART=1..4 (see subpixal_amd/csrc/Makefile)"
+#endif
 #include "spx_rt_emu.h"
 #include "spx_kernels.h"
-#include "spx_aux_kernels.h"
+#if EMU_PART == 4
+#include "spx_aux_kernels.h"      // plain (non-template) kernels: one object only
+#endif
 #include "spx_kernels128.h"
 #include "spx_kernels32.h"
 #include "spx_tables.h"
 
 using namespace spx;
 
+#if EMU_PART == 4
 extern "C" int emu_lds_bytes(int U) {
     int wb = host::window_blocks(U);
     return Lds<2>::total(wb > 0 ? 16 * wb : 0);
 }
+#endif
 
-static int64_t g_grid = 0;     // 0: one workgroup per item; else grid-stride over the batch
+#if EMU_PART == 4
+int64_t g_grid = 0;            // 0: one workgroup per item; else grid-stride over the batch
 extern "C" void emu_set_grid(int64_t g) { g_grid = g; }
+#else
+extern int64_t g_grid;
+#endif
 
-extern "C" int emu_pair(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
-                        int U, int cc_type, double* out, int* status) {
-    if (ny < 5 || nx < 5 || ny > 64 || nx > 64) return -1;
+// ---------------------------------------------------------------------------
+// pair mode and reference mode: the dispatch of spx_capi.hip (32 tile; 64 tile, with its fold
+// path for 65..85 px; period 192 for 86..128 px), for float32 and float64 inputs
+// ---------------------------------------------------------------------------
+#if EMU_PART == 1 || EMU_PART == 2
+template <bool FOLD, typename TIn>
+static int emu_pair64(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
+                      int U, int cc_type, double* out, int* status) {
     const int wb = host::window_blocks(U);
-    if (wb < 0) return -2;
     std::vector<float> tw = host::make_twiddles(128);
     std::vector<float> kt;
     if (wb > 0) kt = host::make_ktab(128, U, 16 * wb);
@@ -31,26 +48,136 @@ extern "C" int emu_pair(const float* ref, const float* img, int64_t nbatch, int 
         rt::launch(g_grid > 0 && g_grid < nbatch ? g_grid : nbatch, kThreads, fn, Lds<2>::total(16 * wb));
     };
     switch (wb) {
-    case 0: run([&] { pair_kernel<2, 0>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
-    case 1: run([&] { pair_kernel<2, 1>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
-    case 2: run([&] { pair_kernel<2, 2>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
-    case 3: run([&] { pair_kernel<2, 3>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
-    default: run([&] { pair_kernel<2, 4>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 0: run([&] { pair_kernel<2, 0, 0, FOLD, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 1: run([&] { pair_kernel<2, 1, 0, FOLD, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 2: run([&] { pair_kernel<2, 2, 0, FOLD, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 3: run([&] { pair_kernel<2, 3, 0, FOLD, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    default: run([&] { pair_kernel<2, 4, 0, FOLD, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
     }
     return 0;
 }
 
-extern "C" int emu_disp5(const float* ref, const float* im4, int64_t nbatch, int ny, int nx,
-                         int cc_type, float* icc, double* out, int* status) {
-    if (ny < 3 || nx < 3 || ny > 64 || nx > 64) return -1;
-    std::vector<float> tw = host::make_twiddles(128);
+template <int C, typename TIn>
+static int emu_pair_big(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx, int U,
+                        int cc_type, double* out, int* status) {
+    const int wb = host::window_blocks(U);
+    std::vector<float> tw = host::make_twiddles(64 * C);
+    std::vector<float> kt;
+    if (wb > 0) kt = host::make_ktab_big(64 * C, U, 16 * wb);
     const cf* twp = reinterpret_cast<const cf*>(tw.data());
-    rt::launch(nbatch, kThreads,
-               [&] { disp5_kernel<2>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status); },
-               Lds<2>::total(0));
+    const float* ktp = kt.empty() ? nullptr : kt.data();
+    const int64_t grid = g_grid > 0 && g_grid < nbatch ? g_grid : nbatch;
+    std::vector<float> ws((size_t)grid * (LdsBig<C>::kWsBytes / sizeof(float)));
+    float* wsp = ws.data();
+    auto run = [&](auto fn) { rt::launch(grid, kThreads, fn, LdsBig<C>::total(16 * wb)); };
+    switch (wb) {
+    case 0: run([&] { pair128_kernel<C, 0, 0, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    case 1: run([&] { pair128_kernel<C, 1, 0, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    case 2: run([&] { pair128_kernel<C, 2, 0, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    case 3: run([&] { pair128_kernel<C, 3, 0, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    default: run([&] { pair128_kernel<C, 4, 0, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
+    }
     return 0;
 }
 
+template <typename TIn>
+static int emu_pair32_t(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
+                        int U, int cc_type, double* out, int* status) {
+    const int wb = host::window_blocks(U);
+    std::vector<float> tw = host::make_twiddles(64);
+    std::vector<float> kt;
+    if (wb > 0) kt = host::make_ktab32(U, 16 * wb);
+    const cf* twp = reinterpret_cast<const cf*>(tw.data());
+    const float* ktp = kt.empty() ? nullptr : kt.data();
+    int64_t grid = (nbatch + 3) / 4;
+    if (g_grid > 0 && g_grid < grid) grid = g_grid;
+    auto run = [&](auto fn) { rt::launch(grid, kThreads, fn, Lds32::total(16 * (wb > 0 ? wb : 1))); };
+    switch (wb) {
+    case 0: run([&] { pair32_kernel<0, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 1: run([&] { pair32_kernel<1, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 2: run([&] { pair32_kernel<2, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 3: run([&] { pair32_kernel<3, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    default: run([&] { pair32_kernel<4, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    }
+    return 0;
+}
+
+// tile: 0 = the product's choice, else force 32 / 64 / 192 / 256 (period of the big path)
+template <typename TIn>
+static int emu_pair_t(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx, int U,
+                      int cc_type, double* out, int* status, int tile) {
+    if (ny < 5 || nx < 5 || ny > 128 || nx > 128) return -1;
+    if (host::window_blocks(U) < 0) return -2;
+    const int n = ny > nx ? ny : nx;
+    if (tile == 0) tile = n <= 32 ? 32 : (n <= 85 ? 64 : 192);
+    if (tile == 32 && n <= 32) return emu_pair32_t<TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
+    if (tile == 64 && n <= 64) return emu_pair64<false, TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
+    if (tile == 64 && n <= 85) return emu_pair64<true, TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
+    if (tile == 192) return emu_pair_big<3, TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
+    if (tile == 256) return emu_pair_big<4, TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
+    return -3;
+}
+#if EMU_PART == 1
+extern "C" int emu_pair_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx, int U,
+                            int cc_type, double* out, int* status, int tile) {
+    return emu_pair_t<float>(ref, img, nbatch, ny, nx, U, cc_type, out, status, tile);
+}
+#else
+extern "C" int emu_pair_f64(const double* ref, const double* img, int64_t nbatch, int ny, int nx, int U,
+                            int cc_type, double* out, int* status, int tile) {
+    return emu_pair_t<double>(ref, img, nbatch, ny, nx, U, cc_type, out, status, tile);
+}
+#endif
+#endif   // EMU_PART 1, 2
+
+#if EMU_PART == 3
+template <typename TIn>
+static int emu_disp5_t(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, int nx,
+                       int cc_type, float* icc, double* out, int* status) {
+    if (ny < 3 || nx < 3 || ny > 128 || nx > 128) return -1;
+    const int n = ny > nx ? ny : nx;
+    if (n <= 32) {
+        std::vector<float> tw = host::make_twiddles(64);
+        const cf* twp = reinterpret_cast<const cf*>(tw.data());
+        rt::launch((nbatch + 3) / 4, kThreads, [&] {
+            disp5_32_kernel<TIn>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status);
+        }, Lds32::total(16));
+        return 0;
+    }
+    if (n <= 85) {
+        std::vector<float> tw = host::make_twiddles(128);
+        const cf* twp = reinterpret_cast<const cf*>(tw.data());
+        if (n > 64)
+            rt::launch(nbatch, kThreads,
+                       [&] { disp5_kernel<2, true, TIn>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status); },
+                       Lds<2>::total(0));
+        else
+            rt::launch(nbatch, kThreads,
+                       [&] { disp5_kernel<2, false, TIn>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status); },
+                       Lds<2>::total(0));
+        return 0;
+    }
+    std::vector<float> tw = host::make_twiddles(192);
+    const cf* twp = reinterpret_cast<const cf*>(tw.data());
+    std::vector<float> ws((size_t)nbatch * (kWs96Bytes / sizeof(float)));
+    float* wsp = ws.data();
+    rt::launch(nbatch, kThreads, [&] {
+        disp5_128_kernel<3, TIn>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, wsp);
+    }, LdsBig<3>::total(0));
+    return 0;
+}
+extern "C" int emu_disp5_f32(const float* ref, const float* im4, int64_t nbatch, int ny, int nx,
+                             int cc_type, float* icc, double* out, int* status) {
+    return emu_disp5_t<float>(ref, im4, nbatch, ny, nx, cc_type, icc, out, status);
+}
+extern "C" int emu_disp5_f64(const double* ref, const double* im4, int64_t nbatch, int ny, int nx,
+                             int cc_type, float* icc, double* out, int* status) {
+    return emu_disp5_t<double>(ref, im4, nbatch, ny, nx, cc_type, icc, out, status);
+}
+
+#endif   // EMU_PART 3
+
+#if EMU_PART == 4
 extern "C" int emu_find_peak(const double* image, const uint8_t* mask, const double* guess,
                              int64_t nbatch, int ny, int nx, int wx, int wy, int sbx, int sby,
                              double* out, int* status) {
@@ -79,61 +206,6 @@ extern "C" int emu_gen_pairs(uint64_t seed, int64_t first, int64_t nbatch, int n
     return 0;
 }
 
-template <int C>
-static int emu_pair_big(const float* ref, const float* img, int64_t nbatch, int ny, int nx, int U,
-                        int cc_type, double* out, int* status) {
-    const int wb = host::window_blocks(U);
-    if (wb < 0) return -2;
-    std::vector<float> tw = host::make_twiddles(64 * C);
-    std::vector<float> kt;
-    if (wb > 0) kt = host::make_ktab_big(64 * C, U, 16 * wb);
-    const cf* twp = reinterpret_cast<const cf*>(tw.data());
-    const float* ktp = kt.empty() ? nullptr : kt.data();
-    const int64_t grid = g_grid > 0 && g_grid < nbatch ? g_grid : nbatch;
-    std::vector<float> ws((size_t)grid * (LdsBig<C>::kWsBytes / sizeof(float)));
-    float* wsp = ws.data();
-    auto run = [&](auto fn) { rt::launch(grid, kThreads, fn, LdsBig<C>::total(16 * wb)); };
-    switch (wb) {
-    case 0: run([&] { pair128_kernel<C, 0>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
-    case 1: run([&] { pair128_kernel<C, 1>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
-    case 2: run([&] { pair128_kernel<C, 2>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
-    case 3: run([&] { pair128_kernel<C, 3>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
-    default: run([&] { pair128_kernel<C, 4>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status, wsp); }); break;
-    }
-    return 0;
-}
-
-extern "C" int emu_pair128(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
-                           int U, int cc_type, double* out, int* status) {
-    if (ny < 5 || nx < 5 || ny > 128 || nx > 128) return -1;
-    return emu_pair_big<4>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
-}
-
-extern "C" int emu_pair96(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
-                          int U, int cc_type, double* out, int* status) {
-    if (ny < 5 || nx < 5 || ny > 96 || nx > 96) return -1;
-    return emu_pair_big<3>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
-}
-
-extern "C" int emu_disp5_128(const float* ref, const float* im4, int64_t nbatch, int ny, int nx,
-                             int cc_type, float* icc, double* out, int* status) {
-    if (ny < 3 || nx < 3 || ny > 128 || nx > 128) return -1;
-    const bool t96 = ny <= 96 && nx <= 96;
-    std::vector<float> tw = host::make_twiddles(t96 ? 192 : 256);
-    const cf* twp = reinterpret_cast<const cf*>(tw.data());
-    std::vector<float> ws((size_t)nbatch * ((t96 ? kWs96Bytes : kWs128Bytes) / sizeof(float)));
-    float* wsp = ws.data();
-    if (t96)
-        rt::launch(nbatch, kThreads, [&] {
-            disp5_128_kernel<3>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, wsp);
-        }, LdsBig<3>::total(0));
-    else
-        rt::launch(nbatch, kThreads, [&] {
-            disp5_128_kernel<4>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, wsp);
-        }, LdsBig<4>::total(0));
-    return 0;
-}
-
 extern "C" int emu_label_bboxes(const int32_t* seg, int fny, int fnx, int max_label, int32_t* boxes,
                                 int32_t* counts) {
     rt::launch(1, 256, [&] { label_bbox_init_kernel(boxes, counts, max_label + 1); }, 0);
@@ -147,37 +219,4 @@ extern "C" int emu_blot_affine4(const float* src, int64_t nbatch, int sny, int s
     rt::launch(3, 256, [&] { blot_affine4_kernel(src, nbatch, sny, snx, affine, gain, ny, nx, im4); }, 0);
     return 0;
 }
-
-extern "C" int emu_pair32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
-                          int U, int cc_type, double* out, int* status) {
-    if (ny < 5 || nx < 5 || ny > 32 || nx > 32) return -1;
-    const int wb = host::window_blocks(U);
-    if (wb < 0) return -2;
-    std::vector<float> tw = host::make_twiddles(64);
-    std::vector<float> kt;
-    if (wb > 0) kt = host::make_ktab32(U, 16 * wb);
-    const cf* twp = reinterpret_cast<const cf*>(tw.data());
-    const float* ktp = kt.empty() ? nullptr : kt.data();
-    int64_t grid = (nbatch + 3) / 4;
-    if (g_grid > 0 && g_grid < grid) grid = g_grid;
-    auto run = [&](auto fn) { rt::launch(grid, kThreads, fn, Lds32::total(16 * (wb > 0 ? wb : 1))); };
-    switch (wb) {
-    case 0: run([&] { pair32_kernel<0>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
-    case 1: run([&] { pair32_kernel<1>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
-    case 2: run([&] { pair32_kernel<2>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
-    case 3: run([&] { pair32_kernel<3>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
-    default: run([&] { pair32_kernel<4>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
-    }
-    return 0;
-}
-
-extern "C" int emu_disp5_32(const float* ref, const float* im4, int64_t nbatch, int ny, int nx,
-                            int cc_type, float* icc, double* out, int* status) {
-    if (ny < 3 || nx < 3 || ny > 32 || nx > 32) return -1;
-    std::vector<float> tw = host::make_twiddles(64);
-    const cf* twp = reinterpret_cast<const cf*>(tw.data());
-    rt::launch((nbatch + 3) / 4, kThreads, [&] {
-        disp5_32_kernel(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status);
-    }, Lds32::total(16));
-    return 0;
-}
+#endif   // EMU_PART 4

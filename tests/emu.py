@@ -38,30 +38,37 @@ def set_grid(g):
     lib().emu_set_grid(ctypes.c_int64(g))
 
 
-def pair(ref, img, upsample=1, cc=0):
-    ref = np.ascontiguousarray(ref, np.float32)
-    img = np.ascontiguousarray(img, np.float32)
+def _in_dtype(*arrays):
+    """float64 arrays go to the float64-input kernels, everything else is float32"""
+    return np.float64 if all(np.asarray(a).dtype == np.float64 for a in arrays) else np.float32
+
+
+def pair(ref, img, upsample=1, cc=0, tile=0):
+    """tile: 0 = the product's dispatch (spx_capi.hip), else force the 32 / 64 tile or the
+    period-192 / 256 path"""
+    dt = _in_dtype(ref, img)
+    ref = np.ascontiguousarray(ref, dt)
+    img = np.ascontiguousarray(img, dt)
     n = ref.shape[0]
     out = np.zeros((n, 2))
     st = np.zeros(n, np.int32)
-    side = max(ref.shape[1:])
-    fn = (lib().emu_pair32 if side <= 32 else lib().emu_pair if side <= 64 else
-          lib().emu_pair96 if side <= 96 else lib().emu_pair128)
-    rc = fn(_p(ref, _fp), _p(img, _fp), ctypes.c_int64(n), ref.shape[1], ref.shape[2],
-            int(upsample), int(cc), _p(out, _dp), _p(st, _ip))
+    fn, pt = (lib().emu_pair_f64, _dp) if dt == np.float64 else (lib().emu_pair_f32, _fp)
+    rc = fn(_p(ref, pt), _p(img, pt), ctypes.c_int64(n), ref.shape[1], ref.shape[2],
+            int(upsample), int(cc), _p(out, _dp), _p(st, _ip), int(tile))
     assert rc == 0, rc
     return out, st
 
 
 def disp5(ref, im4, cc=1):
-    ref = np.ascontiguousarray(ref, np.float32)
-    im4 = np.ascontiguousarray(im4, np.float32)
+    dt = _in_dtype(ref, im4)
+    ref = np.ascontiguousarray(ref, dt)
+    im4 = np.ascontiguousarray(im4, dt)
     n, ny, nx = ref.shape
     out = np.zeros((n, 2))
     st = np.zeros(n, np.int32)
     icc = np.zeros((n, 2 * ny, 2 * nx), np.float32)
-    fn = lib().emu_disp5_128 if max(ny, nx) > 64 else (lib().emu_disp5_32 if max(ny, nx) <= 32 else lib().emu_disp5)
-    rc = fn(_p(ref, _fp), _p(im4, _fp), ctypes.c_int64(n), ny, nx, int(cc),
+    fn, pt = (lib().emu_disp5_f64, _dp) if dt == np.float64 else (lib().emu_disp5_f32, _fp)
+    rc = fn(_p(ref, pt), _p(im4, pt), ctypes.c_int64(n), ny, nx, int(cc),
             _p(icc, _fp), _p(out, _dp), _p(st, _ip))
     assert rc == 0, rc
     return out, st, icc

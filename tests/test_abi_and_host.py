@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_ffi.EXPORTED_SYMBOLS) == names
-    assert lib.spx_abi_version() == 1
+    assert lib.spx_abi_version() == 2
 
 
 def test_argument_errors_without_gpu():
@@ -37,11 +37,12 @@ def test_argument_errors_without_gpu():
     assert lib.spx_workspace_bytes_displacement5(10, 64, 64, 1) == 10 * 4 * 64 * 64 * 4
     assert lib.spx_workspace_bytes_displacement5(10, 64, 64, 0) == 0
     assert lib.spx_workspace_bytes_xcorr(10, 64, 64) == 0
-    # 96 tile: 9 complex class planes of 64x64 + the 192 x (192+4) convolution, per workgroup;
-    # 128 tile: 16 planes + 256 x (256+4)
-    assert lib.spx_workspace_bytes_xcorr(10, 65, 64) == 10 * (9 * 2 * 64 * 64 + 192 * 196) * 4
-    assert lib.spx_workspace_bytes_xcorr(10, 97, 64) == 10 * (16 * 2 * 64 * 64 + 256 * 260) * 4
-    assert lib.spx_workspace_bytes_displacement5(10, 65, 64, 0) == 10 * (9 * 2 * 64 * 64 + 192 * 196) * 4
+    # cutouts up to 85 px stay in LDS (64 tile's fold path, period 128); above that the period-192
+    # path: 9 complex class planes of 64x64 + the 192 x (192+4) convolution, per workgroup
+    assert lib.spx_workspace_bytes_xcorr(10, 85, 64) == 0
+    assert lib.spx_workspace_bytes_xcorr(10, 86, 64) == 10 * (9 * 2 * 64 * 64 + 192 * 196) * 4
+    assert lib.spx_workspace_bytes_xcorr(10, 97, 128) == 10 * (9 * 2 * 64 * 64 + 192 * 196) * 4
+    assert lib.spx_workspace_bytes_displacement5(10, 86, 64, 0) == 10 * (9 * 2 * 64 * 64 + 192 * 196) * 4
     # argument validation happens before any HIP call
     assert lib.spx_xcorr_refine_f32(None, None, 1, 64, 64, 1, 0, None, None, None, 0, None) == -1
     assert lib.spx_xcorr_refine_f32(None, None, 0, 64, 64, 1, 0, None, None, None, 0, None) == 0
@@ -50,7 +51,11 @@ def test_argument_errors_without_gpu():
     p = ctypes.cast(buf, ctypes.c_void_p)
     assert lib.spx_xcorr_refine_f32(p, p, 1, 129, 64, 1, 0, p, None, None, 0, None) == -2
     assert b'5..128' in lib.spx_last_error()
-    assert lib.spx_xcorr_refine_f32(p, p, 1, 65, 64, 1, 0, p, None, None, 0, None) == -4     # 128 tile needs workspace
+    assert lib.spx_xcorr_refine_f32(p, p, 1, 86, 64, 1, 0, p, None, None, 0, None) == -4     # period 192 needs workspace
+    assert lib.spx_xcorr_refine_f64(p, p, 1, 86, 64, 1, 0, p, None, None, 0, None) == -4
+    assert lib.spx_xcorr_refine_f64(None, None, 1, 64, 64, 1, 0, None, None, None, 0, None) == -1
+    assert lib.spx_find_displacement5_f64(p, p, 1, 128, 128, 0, p, None, p, None, 0, None) == -4
+    assert lib.spx_shutdown() == 0           # nothing initialised: nothing to free
     assert lib.spx_xcorr_refine_f32(p, p, 1, 64, 64, 60, 0, p, None, None, 0, None) == -2
     assert lib.spx_find_displacement5_f32(p, p, 1, 128, 128, 0, p, None, p, None, 0, None) == -4
     assert lib.spx_find_peak_f64(p, None, None, 1, 8, 8, 0, 5, 0, 0, p, None, None) == -1

@@ -60,6 +60,52 @@ def test_graph_capture_reference_mode():
     assert torch.equal(out, eager)
 
 
+@pytest.mark.parametrize('n,up', [(32, 7), (80, 9), (96, 11), (128, 21)])
+def test_capture_every_kernel_family_without_prior_eager_call(n, up):
+    """spx_prepare(upsample) builds the tables of EVERY kernel family and raises
+    every kernel's LDS limit, so the very first launch at a (shape, upsample) can already sit
+    inside a stream capture -- 32 tile, 64 tile's fold path, period-192 path; pair mode and
+    reference mode; float32 and float64 inputs.  Each upsample here is used nowhere else in the
+    suite, so no earlier eager call can have built its tables."""
+    import torch
+    import datagen
+    from subpixal_amd import cc, device
+    device.prepare(up)
+    ref, img, truth = _pairs(100 + n, count=512, n=n)
+    r5, m4, _ = datagen.dither_batch(n, 8, n)
+    r5 = torch.as_tensor(r5, device='cuda')
+    m4 = torch.as_tensor(m4, device='cuda')
+    ref64, img64 = ref[:64].double(), img[:64].double()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out, status = cc.xcorr_refine_batch(ref, img, upsample=up, return_status=True)
+        out64 = cc.xcorr_refine_batch(ref64, img64, upsample=up)
+        d5 = cc.find_displacement_batch(r5, m4, cc_type='NCC')
+        d5_64 = cc.find_displacement_batch(r5.double(), m4.double(), cc_type='ZNCC')
+    graph.replay()
+    torch.cuda.synchronize()
+    assert int(status.abs().max()) == 0
+    if n > 32:                       # (the generator's sigma 4..6 spots are clipped by a 32 px tile)
+        assert float((out - truth).abs().max()) < 1e-3
+    assert float((out64 - out[:64]).abs().max()) < 1e-4
+    eager = cc.xcorr_refine_batch(ref, img, upsample=up)
+    assert torch.equal(out, eager)
+    assert torch.equal(d5, cc.find_displacement_batch(r5, m4, cc_type='NCC'))
+    assert torch.equal(d5_64, cc.find_displacement_batch(r5.double(), m4.double(), cc_type='ZNCC'))
+
+
+def test_shutdown_frees_and_rebuilds_tables():
+    import torch
+    from subpixal_amd import cc, device
+    ref, img, truth = _pairs(31, count=256)
+    a = cc.xcorr_refine_batch(ref, img, upsample=10)
+    torch.cuda.synchronize()
+    device.shutdown()
+    b = cc.xcorr_refine_batch(ref, img, upsample=10)       # tables rebuilt on first use
+    assert torch.equal(a, b)
+
+
 def test_two_streams_are_independent():
     import torch
     from subpixal_amd import cc, device

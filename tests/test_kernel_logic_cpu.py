@@ -35,8 +35,8 @@ def test_pair_mode_grid_stride_pipeline():
     assert np.array_equal(st, est)
 
 
-def test_pair_mode_128_tile():
-    """cutouts above 64 px: period-256 path (16 classes, workspace, radix-4 combine)"""
+def test_pair_mode_period_192():
+    """cutouts of 86..128 px: period-192 path (9 classes, radix-3 fold and combine, workspace)"""
     ref, img, truth = datagen.pair_batch(5, 1, 128)
     got, st = emu.pair(ref, img, 2)
     exp, est = orc.xcorr_refine_batch(ref, img, 2)
@@ -45,21 +45,80 @@ def test_pair_mode_128_tile():
     got, st = emu.pair(r[None], i[None], 1, 2)
     e = orc.xcorr_refine(r, i, 1, 'ZNCC')
     assert np.max(np.abs(got[0] - np.array(e))) < 2e-5
-
-
-def test_pair_mode_96_tile():
-    """cutouts of 65..96 px: period-192 path (9 classes, radix-3 fold and combine)"""
     ref, img, truth = datagen.pair_batch(6, 2, 96)
     got, st = emu.pair(ref, img, 10)
     exp, est = orc.xcorr_refine_batch(ref, img, 10)
     assert np.max(np.abs(got - exp)) < 1e-4 and np.array_equal(st, est)
     assert np.max(np.abs(got - truth)) < 2e-4
-    r, i = datagen.pair_set(65, 90, -1.3, 0.6, 6.0, 0.8, np.float32)
-    for up, name, code in ((1, 'CC', 0), (2, 'NCC', 1)):
-        got, st = emu.pair(r[None], i[None], up, code)
-        e = orc.xcorr_refine(r, i, up, name)
-        assert np.max(np.abs(got[0] - np.array(e))) < 2e-5
-    assert orc.tile_size(65, 90) == 96 and orc.tile_size(97, 5) == 128 and orc.tile_size(64, 64) == 64
+
+
+def test_pair_mode_fold_path():
+    """cutouts of 65..85 px on the 64 tile: period 128 = the smallest alias-free period for the
+    'same' window; the samples beyond index 63 are folded into the four parity classes in LDS"""
+    rng = np.random.default_rng(8)
+    for (ny, nx) in ((65, 65), (85, 85), (70, 81), (85, 9), (12, 66)):
+        r, i = datagen.pair_set(ny, nx, rng.uniform(-2, 2), rng.uniform(-2, 2), min(ny, nx) / 12 + 1, 1.3,
+                                np.float32, noise_seed=7, noise_level=0.01)
+        for up, name, code in ((1, 'CC', 0), (2, 'NCC', 1), (10, 'ZNCC', 2)):
+            got, st = emu.pair(r[None], i[None], up, code)
+            s2 = []
+            e = orc.xcorr_refine(r, i, up, name, _status=s2)
+            assert np.max(np.abs(got[0] - np.array(e))) < (1e-4 if up > 2 else 2e-5), (ny, nx, up)
+            assert st[0] == s2[-1]
+    # at integer lags every alias-free period gives the same numbers: period 128 == period 192
+    r, i = datagen.pair_set(80, 77, 1.3, -0.4, 5.0, 1.0, np.float32)
+    a, _ = emu.pair(r[None], i[None], 1, 0)
+    b, _ = emu.pair(r[None], i[None], 1, 0, tile=192)
+    assert np.max(np.abs(a - b)) < 2e-6
+    assert orc.fft_period(65, 85) == 128 and orc.fft_period(86, 5) == 192 and orc.fft_period(128, 128) == 192
+    assert orc.fft_period(64, 64) == 128 and orc.fft_period(32, 20) == 64
+    # reference mode on the fold path
+    r5, m4, _ = datagen.dither_batch(3, 1, 77)
+    d, st, icc = emu.disp5(r5, m4, 1)
+    e, est = orc.find_displacement_batch(r5, m4, 'NCC')
+    eicc = orc.build_icc(r5[0], *m4[0], cc_type='NCC')[0]
+    assert np.abs(d - e).max() < 2e-5 and np.array_equal(st, est)
+    assert np.abs(icc[0] - eicc).max() < 3e-6 * np.abs(eicc).max()
+
+
+def test_nonfinite_pixels_are_flagged_not_fatal():
+    """one NaN pixel made the 96/128 tiles index far outside their workspace.  A NaN
+    makes every lag NaN; numpy.argmax then returns 0 and find_peak the integer position (0, 0)
+    (centroid.py:114, 171-172): same result here, with status ST_NONFINITE, on every tile."""
+    for n in (20, 64, 80, 128):
+        r, i = datagen.pair_set(n, n, 1.3, -0.7, 3.0, 1.0, np.float32)
+        for bad in (np.nan, np.inf):
+            i2 = i.copy()
+            i2[3, 4] = bad
+            for up in (1, 10):
+                got, st = emu.pair(np.stack([r, r]), np.stack([i2, i]), up, 0)
+                s2 = []
+                e = orc.xcorr_refine(r, i2, up, 'CC', _status=s2)
+                assert st[0] == 6 == s2[-1] and st[1] == 0
+                assert tuple(got[0]) == e == (-((n - 1) // 2), -((n - 1) // 2))
+        r5, m4, _ = datagen.dither_batch(3, 1, n)
+        m4 = m4.copy()
+        m4[0, 2, 5, 5] = np.nan
+        d, st, _ = emu.disp5(r5, m4, 1)
+        assert st[0] == 6 and tuple(d[0]) == (-((n - 1) // 2), -((n - 1) // 2))
+
+
+def test_float64_inputs_use_float64_masks_and_statistics(golden_dir):
+    """float64 cutouts: cc.py:135's `!= 0` mask and the pooled statistics are taken from the float64
+    values (tails that underflow in float32 stay in the mask), closing the 5e-3 px ZNCC gap of r1"""
+    g = np.load(os.path.join(golden_dir, 'find_displacement.npz'))
+    sel = [i for i in range(len(g['dx'])) if g['dtype'][i] == 1 and g['cc_type'][i] == 2][::6]
+    assert len(sel) >= 8
+    for i in sel:
+        ny, nx = int(g['ny'][i]), int(g['nx'][i])
+        ims = datagen.dither_set(ny, nx, g['tx'][i], g['ty'][i], g['sigma'][i], g['amp'][i], np.float64,
+                                 int(g['noise_seed'][i]), g['noise_level'][i], int(g['zero_mode'][i]))
+        out, st, icc = emu.disp5(ims[0][None], np.stack(ims[1:])[None], 2)
+        assert abs(out[0, 0] - g['dx'][i]) < 2e-5 and abs(out[0, 1] - g['dy'][i]) < 2e-5, (ny, nx)
+    r, i = datagen.pair_set(64, 64, 0.6, -1.2, 4.0, 1.0, np.float64)
+    got, st = emu.pair(r[None], i[None], 10, 2)
+    e = orc.xcorr_refine(r, i, 10, 'ZNCC')
+    assert np.max(np.abs(got[0] - np.array(e))) < 1e-4
 
 
 def test_pair_mode_32_tile():

@@ -14,10 +14,11 @@ import datagen                                         # noqa: E402
 import subpixal_amd as spx                             # noqa: E402
 
 N = int(os.environ.get('N', 100000))
-for ny, nx in ((64, 64), (64, 60), (63, 63), (48, 48), (40, 56), (33, 33), (32, 32), (24, 24), (17, 31), (128, 128), (100, 100), (65, 65)):
+for ny, nx in ((64, 64), (64, 60), (63, 63), (48, 48), (40, 56), (33, 33), (32, 32), (24, 24), (17, 31), (65, 65), (72, 72), (85, 85),
+               (80, 40), (86, 86), (96, 96), (100, 100), (128, 128)):
     ref, img, truth = datagen.pair_batch(3, 64, max(ny, nx))
     ref = np.ascontiguousarray(ref[:, :ny, :nx]); img = np.ascontiguousarray(img[:, :ny, :nx])
-    n = N if max(ny, nx) <= 64 else N // 5
+    n = N if max(ny, nx) <= 85 else N // 5
     r = torch.from_numpy(ref).cuda().repeat(n // 64, 1, 1).contiguous()
     m = torch.from_numpy(img).cuda().repeat(n // 64, 1, 1).contiguous()
     spx.xcorr_refine_batch(r, m, upsample=10)
