@@ -148,14 +148,16 @@ def flops_per_pair(tile, upsample):
     return FLOPS_PER_PAIR.get((fam, wb))
 
 
-def kernel_commit():
-    """Commit the kernel sources were last changed in (ties a PMC traffic file to a build)."""
-    import subprocess
-    try:
-        return subprocess.check_output(['git', '-C', ROOT, 'log', '-1', '--format=%h', '--',
-                                        'subpixal_amd/csrc'], text=True, stderr=subprocess.DEVNULL).strip()
-    except (OSError, subprocess.CalledProcessError):
-        return None
+def kernel_build():
+    """Fingerprint of the kernel sources (ties a PMC traffic file to the build it was measured on;
+    works on the GPU box, where there is no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'subpixal_amd', 'csrc')
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith(('.h', '.hip')):
+            h.update(open(os.path.join(csrc, name), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -268,7 +270,7 @@ def main():
                     'pmc_traffic_%d_u%d.json' % (tile, ups)
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', rnd, name)))
                 if pmc.get('pairs_per_launch') == n_local and pmc.get('tile', TILE) == tile and \
-                        pmc.get('upsample', UPSAMPLE) == ups and pmc.get('kernel_commit') == kernel_commit():
+                        pmc.get('upsample', UPSAMPLE) == ups and pmc.get('kernel_build') == kernel_build():
                     traffic = pmc['hbm_bytes_per_launch']
                     traffic_src = 'profiles/%s/%s' % (rnd, name)
                     break

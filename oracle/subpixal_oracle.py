@@ -345,10 +345,19 @@ def find_displacement(ref_image, image00, image10, image01, image11,
     the interlaced cross-correlation; restates ``cc.py:21-95``."""
     icc, ccs = build_icc(ref_image, image00, image10, image01, image11,
                          cc_type)
-    xm, ym = find_peak(icc, peak_fit_box=5, peak_search_box='all',
-                       _status=_status)
-    if _status is not None and not np.all(np.isfinite(icc)):
-        _status[-1] = STATUS_NONFINITE
+    if np.all(np.isfinite(icc)):
+        xm, ym = find_peak(icc, peak_fit_box=5, peak_search_box='all',
+                           _status=_status)
+    else:
+        # numpy.argmax ranks NaN above everything and returns the first one (centroid.py:114);
+        # what the reference does next depends on where that is (edge rule, or lstsq failing on
+        # NaN): the restatement stops at the integer position and flags the source.  An
+        # overflowed (+inf) correlation is treated the same way.
+        key = np.where(np.isnan(icc), np.inf, icc)
+        jm, im = np.unravel_index(np.argmax(key), key.shape)
+        xm, ym = float(im), float(jm)
+        if _status is not None:
+            _status.append(STATUS_NONFINITE)
     xc = (icc.shape[1] - 1) // 4
     yc = (icc.shape[0] - 1) // 4
     dx = 0.5 * xm - xc

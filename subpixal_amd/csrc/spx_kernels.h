@@ -254,6 +254,11 @@ SPX_DEVICE void block_sum2f(unsigned char* lds_scr, float& a, float& b) {
 SPX_DEVICE bool better(float v, int i, float bv, int bi) {
     return (v > bv) || (v == bv && i < bi);
 }
+// Reference mode: numpy.argmax treats NaN as the maximum and returns the FIRST one
+// (centroid.py:114).  A NaN is ranked as +inf here, so the (value, lowest index) reductions
+// find that position; a best value of +inf afterwards means "non-finite correlation".
+SPX_DEVICE float nan_as_inf(float v) { return v != v ? __builtin_inff() : v; }
+
 // `slot` (0/1) selects one of two scratch areas: consecutive calls alternate slots, and a
 // slot is only rewritten after at least one more workgroup barrier, so no trailing
 // barrier is needed.
@@ -1373,10 +1378,17 @@ SPX_DEVICE void interlace_window_fold(const unsigned char* lds, int ny, int nx, 
             const float tp = d[2][e] + d[3][e], tm = d[2][e] - d[3][e];
             const float vaa = (up + tp) * out_scale, vab = (um + tm) * out_scale;
             const float vba = (up - tp) * out_scale, vbb = (um - tm) * out_scale;
-            if (rowa >= 0 && gxa[e] >= 0) { icc[rowa + gxa[e]] = vaa; if (better(vaa, rowa + gxa[e], m, best)) { m = vaa; best = rowa + gxa[e]; } }
-            if (rowa >= 0 && gxb[e] >= 0) { icc[rowa + gxb[e]] = vab; if (better(vab, rowa + gxb[e], m, best)) { m = vab; best = rowa + gxb[e]; } }
-            if (rowb >= 0 && gxa[e] >= 0) { icc[rowb + gxa[e]] = vba; if (better(vba, rowb + gxa[e], m, best)) { m = vba; best = rowb + gxa[e]; } }
-            if (rowb >= 0 && gxb[e] >= 0) { icc[rowb + gxb[e]] = vbb; if (better(vbb, rowb + gxb[e], m, best)) { m = vbb; best = rowb + gxb[e]; } }
+            auto put = [&](int row, int gx, float v) {
+                if (row >= 0 && gx >= 0) {
+                    icc[row + gx] = v;
+                    v = nan_as_inf(v);
+                    if (better(v, row + gx, m, best)) { m = v; best = row + gx; }
+                }
+            };
+            put(rowa, gxa[e], vaa);
+            put(rowa, gxb[e], vab);
+            put(rowb, gxa[e], vba);
+            put(rowb, gxb[e], vbb);
         }
     }
     bv = m;
@@ -1426,7 +1438,7 @@ SPX_DEVICE void interlace_window(const unsigned char* lds, int ny, int nx, float
             const float v = __builtin_fmaf(fy, t, u) * out_scale;
             const bool ok = rowbase[i] >= 0 && gx[e] >= 0;
             if (ok) icc[rowbase[i] + gx[e]] = v;
-            val[i][e] = ok ? v : ninf;
+            val[i][e] = ok ? nan_as_inf(v) : ninf;
             m = __builtin_fmaxf(m, val[i][e]);
         }
     }
@@ -1468,13 +1480,16 @@ SPX_DEVICE void disp5_body(const TIn* __restrict__ ref, const TIn* __restrict__ 
     }
     rt::block_sync();        // icc (GLOBAL memory) written above is read below by other waves
     block_argmax(scr, bv, bi, 0);
-    const bool nonfinite = bi == kNoIndex;      // NaN everywhere: numpy.argmax -> 0 (see pair_body)
-    if (nonfinite) bi = 0;
+    // a NaN (ranked +inf, see nan_as_inf) or an overflowed correlation: the integer position of
+    // the first one, as numpy.argmax + the integer fallbacks of find_peak give, flagged
+    const bool nonfinite = !(bv < __builtin_inff());
     const int jmax = bi / NX, imax = bi % NX;
-    PeakResult pk = peak_from_argmax(scr, imax, jmax, NX, NY, [&](int x, int y) {
-        return icc[y * NX + x];
-    });
-    if (nonfinite) pk.status = ST_NONFINITE;
+    PeakResult pk;
+    if (nonfinite) {
+        pk.x = (double)imax; pk.y = (double)jmax; pk.status = ST_NONFINITE;
+    } else {
+        pk = peak_from_argmax(scr, imax, jmax, NX, NY, [&](int x, int y) { return icc[y * NX + x]; });
+    }
     if (tid == 0) {
         out[0] = 0.5 * pk.x - (double)((NX - 1) / 4);     // cc.py:89-93
         out[1] = 0.5 * pk.y - (double)((NY - 1) / 4);

@@ -497,18 +497,19 @@ SPX_TKERNEL(256) void disp5_32_kernel(const TIn* __restrict__ ref, const TIn* __
                 const float val = window_value32(wbuf, ny, nx, qy, qx, oscale);
                 const int gi = (2 * qy + oy) * NX + 2 * qx + ox;
                 icc[gi] = val;
-                if (better(val, gi, bv, bi)) { bv = val; bi = gi; }
+                if (better(nan_as_inf(val), gi, bv, bi)) { bv = nan_as_inf(val); bi = gi; }
             }
             rt::wave_sync_mem();     // icc (global) is read back by other lanes for the fit
         }
         wave_argmax(bv, bi);
-        const bool nonfinite = bi == kNoIndex;
-        if (nonfinite) bi = 0;
+        const bool nonfinite = !(bv < __builtin_inff());        // see disp5_body (spx_kernels.h)
         const int jmax = bi / NX, imax = bi % NX;
-        PeakResult pk = peak_fit_wave(fit, imax, jmax, NX, NY, [&](int x, int y) {
-            return icc[(size_t)y * NX + x];
-        });
-        if (nonfinite) pk.status = ST_NONFINITE;
+        PeakResult pk;
+        if (nonfinite) {
+            pk.x = (double)imax; pk.y = (double)jmax; pk.status = ST_NONFINITE;
+        } else {
+            pk = peak_fit_wave(fit, imax, jmax, NX, NY, [&](int x, int y) { return icc[(size_t)y * NX + x]; });
+        }
         if (lane == 0) {
             out_all[2 * p] = 0.5 * pk.x - (double)((NX - 1) / 4);
             out_all[2 * p + 1] = 0.5 * pk.y - (double)((NY - 1) / 4);

@@ -101,6 +101,11 @@ def test_nonfinite_pixels_are_flagged_not_fatal():
         m4[0, 2, 5, 5] = np.nan
         d, st, _ = emu.disp5(r5, m4, 1)
         assert st[0] == 6 and tuple(d[0]) == (-((n - 1) // 2), -((n - 1) // 2))
+        # plain CC: only the dither holding the NaN has a NaN correlation; numpy.argmax returns the
+        # first NaN of the interlaced image (row 1, column 0 for dither 01)
+        d, st, _ = emu.disp5(r5, m4, 0)
+        e, est = orc.find_displacement_batch(r5, m4, 'CC')
+        assert st[0] == 6 == est[0] and np.array_equal(d, e)
 
 
 def test_float64_inputs_use_float64_masks_and_statistics(golden_dir):

@@ -45,7 +45,7 @@ def render(size, xy, amp, sigma, half=14):
     return frame
 
 
-def run(size=4096, nsrc=5000, upsample=10, quiet=False):
+def run(size=4096, nsrc=5000, upsample=10, quiet=False, nclip=3):
     import torch
     import torch.distributed as dist
     from subpixal_amd import cutout, cc
@@ -88,7 +88,7 @@ def run(size=4096, nsrc=5000, upsample=10, quiet=False):
     out = None
     if rank == 0:
         d = d.cpu().numpy()
-        fit = iter_linear_fit(xy, xy + d, fitgeom='general', center=c, nclip=3, sigma=3.0)
+        fit = iter_linear_fit(xy, xy + d, fitgeom='general', center=c, nclip=nclip, sigma=3.0)
         out = dict(fit=fit, true_matrix=f, true_offset=t, shifts=d, true_shifts=xy2 - xy,
                    gpu_seconds=gpu_s)
         if not quiet:

@@ -30,18 +30,29 @@ def main():
     ap.add_argument('--pairs', type=int, default=100000)
     ap.add_argument('--bytes-per-pair', type=int, default=2 * 64 * 64 * 4 + 20)
     ap.add_argument('--build', default='')
+    ap.add_argument('--tile', type=int, default=64)
+    ap.add_argument('--upsample', type=int, default=10)
     a = ap.parse_args()
+    if a.bytes_per_pair == 2 * 64 * 64 * 4 + 20:
+        a.bytes_per_pair = 2 * a.tile * a.tile * 4 + 20
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     fetch_kb, nf = mean_counter(a.fetch_csv, a.kernel, 'FETCH_SIZE')
     write_kb, nw = mean_counter(a.write_csv, a.kernel, 'WRITE_SIZE')
     rd = 2.0 * fetch_kb * 1024.0
     wr = write_kb * 1024.0
     print(json.dumps({
         'command': 'rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 bench.py '
-                   '--steps 3 --warmup 1 --no-cpu-baseline (one pass per counter, tools/gpu_pmc.sh)',
+                   '--steps 3 --warmup 1 --no-cpu-baseline --tile %d --upsample %d (one pass per counter, '
+                   'tools/gpu_pmc.sh)' % (a.tile, a.upsample),
         'kernel': a.kernel,
         'launches_averaged': [nf, nw],
         'pairs_per_launch': a.pairs,
+        'tile': a.tile,
+        'upsample': a.upsample,
         'build': a.build,
+        'kernel_build': bench.kernel_build(),
         'FETCH_SIZE_KB_per_launch': fetch_kb,
         'WRITE_SIZE_KB_per_launch': write_kb,
         'read_bytes_per_launch': rd,
