@@ -450,6 +450,56 @@ template <typename T> SPX_DEVICE float norm_ref(T r, const NormStatsT<T>& ns) {
     return (float)(r / ns.ref_std);
 }
 
+// ---------------------------------------------------------------------------
+// Branch-free fetch of one 4-pixel chunk of the staged operand z = ref + i*flip(img): row y,
+// columns x..x+3 of ref and the same positions of the flipped image (cc.py:114: pixel (y, x) of
+// flip(img) is img[ny-1-y][nx-1-x]).  No control flow around the loads, so a thread's loads of
+// several chunks are all in flight together (one exposed memory latency instead of one per chunk).
+// Chunks outside the cutout load a clamped (valid) address and come back as zeros; a chunk that
+// straddles the row end (nx not a multiple of 4) loads the row's LAST four pixels and shifts.
+// ---------------------------------------------------------------------------
+template <typename TIn> struct ChunkLoad {
+    Quad<TIn> r, t;      // ref[yy][xx-s .. +3],  img[ny-1-yy][nx-4-xx+s .. +3]
+    int s;               // pixels of the chunk beyond the row end (0..3)
+    bool in;             // chunk starts inside the cutout
+};
+template <typename TIn>
+SPX_DEVICE ChunkLoad<TIn> chunk_issue(const TIn* __restrict__ ref, const TIn* __restrict__ img,
+                                      int ny, int nx, int y, int x) {
+    ChunkLoad<TIn> c;
+    c.in = y < ny && x < nx;
+    const int yy = y < ny ? y : ny - 1;
+    const int xx = x < nx ? x : 0;
+    int s = xx + 4 - nx;
+    s = s < 0 ? 0 : s;
+    c.s = s;
+    c.r = load_quad(ref + (int64_t)yy * nx + (xx - s));
+    c.t = load_quad(img + (int64_t)(ny - 1 - yy) * nx + (nx - 4 - xx + s));
+    return c;
+}
+template <typename T> SPX_DEVICE T quad_pick(const Quad<T>& q, int k) {      // q.v[k], k in [0, 4)
+    const T lo = k & 1 ? q.v[1] : q.v[0], hi = k & 1 ? q.v[3] : q.v[2];
+    return k & 2 ? hi : lo;
+}
+// (re, im)[e] = (ref, flipped img) at column x + e, normalised (cc.py:144-154); zeros outside
+template <typename TIn>
+SPX_DEVICE void chunk_unpack(const ChunkLoad<TIn>& c, const NormStatsT<TIn>& ns, float (&re)[4],
+                             float (&im)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool ok = c.in && e + c.s < 4;
+        const TIn ri = quad_pick(c.r, (e + c.s) & 3);
+        const TIn mi = quad_pick(c.t, (3 - c.s - e) & 3);
+        float r = (float)ri, m = (float)mi;
+        if (ns.active) {
+            m = norm_im(mi, ns);
+            r = norm_ref(ri, ns);
+        }
+        re[e] = ok ? r : 0.0f;
+        im[e] = ok ? m : 0.0f;
+    }
+}
+
 // Staged-input geometry.  Cutouts up to 64 px: 64 rows of ZS = 72 floats.  FOLD (65..85 px,
 // the period-128 transform of a cutout longer than half the period): the whole cutout plus
 // zero padding in an 88 x 88 region of row stride 88 (8 consecutive columns of 8 consecutive
@@ -503,40 +553,25 @@ SPX_DEVICE void stage_pair(unsigned char* lds, const TIn* __restrict__ ref,
         return;
     }
     // every other shape: 4-pixel chunks, one 16-byte load each (4-byte aligned is enough on
-    // gfx950) when the chunk lies inside its row, element loads for the chunk that straddles
-    // the row end, zeros in the padding; the image is read back to front (cc.py:114)
+    // gfx950), all issued before the first is used (chunk_issue); zeros in the padding; the
+    // image is read back to front (cc.py:114)
     constexpr int kIters = (G::ROWS * G::CHUNKS + kThreads - 1) / kThreads;
+    ChunkLoad<TIn> ld[kIters];
+#pragma unroll
+    for (int i = 0; i < kIters; ++i) {
+        const int idx = tid + i * kThreads;
+        const int y = FOLD ? idx / G::CHUNKS : idx >> 4;
+        const int x = (FOLD ? idx - y * G::CHUNKS : (idx & 15)) << 2;
+        ld[i] = chunk_issue(ref, img, ny, nx, y, x);        // (rows beyond the staged region: y >= ny, zeros)
+    }
 #pragma unroll
     for (int i = 0; i < kIters; ++i) {
         const int idx = tid + i * kThreads;
         if (FOLD && idx >= G::ROWS * G::CHUNKS) break;
         const int y = FOLD ? idx / G::CHUNKS : idx >> 4;
         const int x = (FOLD ? idx - y * G::CHUNKS : (idx & 15)) << 2;
-        float rr[4] = {0.f, 0.f, 0.f, 0.f}, mm[4] = {0.f, 0.f, 0.f, 0.f};
-        if (y < ny && x < nx) {
-            const TIn* rrow = ref + (int64_t)y * nx + x;
-            const TIn* mrow = img + (int64_t)(ny - 1 - y) * nx + (nx - 1 - x);
-            TIn ri[4] = {0, 0, 0, 0}, mi[4] = {0, 0, 0, 0};
-            if (x + 3 < nx) {
-                const Quad<TIn> r = load_quad(rrow);
-                const Quad<TIn> t = load_quad(mrow - 3);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { ri[e] = r.v[e]; mi[e] = t.v[3 - e]; }
-            } else {
-                for (int e = 0; e < 4 && x + e < nx; ++e) { ri[e] = rrow[e]; mi[e] = mrow[-e]; }
-            }
-            const int nin = nx - x < 4 ? nx - x : 4;          // pixels of the chunk inside the cutout
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (ns.active && e < nin) {
-                    mm[e] = norm_im(mi[e], ns);        // cc.py:144-148: masked pixels only
-                    rr[e] = norm_ref(ri[e], ns);       // cc.py:153-154: all pixels
-                } else {
-                    mm[e] = (float)mi[e];
-                    rr[e] = (float)ri[e];
-                }
-            }
-        }
+        float rr[4], mm[4];
+        chunk_unpack(ld[i], ns, rr, mm);
         *reinterpret_cast<f32x4*>(zre + y * G::ZS + x) = f32x4{rr[0], rr[1], rr[2], rr[3]};
         *reinterpret_cast<f32x4*>(zim + y * G::ZS + x) = f32x4{mm[0], mm[1], mm[2], mm[3]};
 #pragma unroll

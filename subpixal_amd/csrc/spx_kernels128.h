@@ -54,103 +54,72 @@ constexpr size_t kWs128Bytes = LdsBig<4>::kWsBytes;
 constexpr size_t kWs96Bytes = LdsBig<3>::kWsBytes;
 struct __attribute__((packed, aligned(4))) F32x4U { float v[4]; };   // 16-byte load, 4-byte aligned
 
-// one 64x64 quadrant block (sy, sx) of z = ref + i*bal*flip(img), normalised, into LDS
-template <typename TIn>
-SPX_DEVICE void stage_block128(unsigned char* lds, const TIn* __restrict__ ref,
-                               const TIn* __restrict__ img, int ny, int nx, int sy, int sx,
-                               const NormStatsT<TIn>& ns, float bal) {
-    typedef Lds128 L;
+// Staging of one round (all classes (cy, *)): the radix-C fold ALONG Y of z = ref + i*bal*flip(img)
+//   u_cy[y'][x] = z[y'][x] + w_C^cy z[y'+64][x],   y' in [0,64), x in [0,128)
+// (the cutout spans at most two 64-blocks per axis), normalised, into two LDS planes of 64 rows x
+// US floats that together fill the exchange region exactly.  One pass over the pair per round:
+// every thread issues its 16-byte loads back to back (one exposed memory latency per half),
+// then folds and stores.  The waves then fold along x themselves: v = u[x'] + w_C^cx u[x'+64].
+constexpr int kUS = 136;         // row stride (floats): 128 + 8, conflict-free 8x8 tile reads
+template <int C, typename TIn>
+SPX_DEVICE void stage_yfold(unsigned char* lds, const TIn* __restrict__ ref,
+                            const TIn* __restrict__ img, int ny, int nx,
+                            const NormStatsT<TIn>& ns, float bal, int cy, float (&ssq)[2]) {
+    typedef LdsBig<C> L;
+    static_assert(2 * 64 * kUS * 4 <= L::XCH_BYTES, "the folded slab must fit the exchange region");
     const int tid = fresh_tid();
-    float* zre = reinterpret_cast<float*>(lds + L::R_OFF);
-    float* zim = zre + 64 * L::ZS;
-    // 4-pixel chunks: one 16-byte load each (4-byte aligned is enough on gfx950) when the chunk
-    // lies inside its row, element loads for the chunk that straddles the row end, zeros in the
-    // padding; the image is read back to front (cc.py:114)
+    float* ure = reinterpret_cast<float*>(lds + L::R_OFF);
+    float* uim = ure + 64 * kUS;
+    // w_C^cy = exp(-2 pi i cy / C)
+    const float wr = cy == 0 ? 1.0f : (C == 4 ? (cy == 2 ? -1.0f : 0.0f) : -0.5f);
+    const float wi = cy == 0 ? 0.0f : (C == 4 ? (cy == 1 ? -1.0f : (cy == 3 ? 1.0f : 0.0f))
+                                              : (cy == 1 ? -0.86602540378443865f : 0.86602540378443865f));
+    // 64 rows x 32 chunks = 2048 chunk pairs (top row y', bottom row y'+64), 8 per thread, in two
+    // batches of 4: the 16 loads of a batch are in flight together (chunk_issue is branch-free)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + i * kThreads;
-        const int yl = idx >> 4, x4 = idx & 15;
-        const int y = yl + 64 * sy, x = 4 * x4 + 64 * sx;
-        float rr[4] = {0.f, 0.f, 0.f, 0.f}, mm[4] = {0.f, 0.f, 0.f, 0.f};
-        if (y < ny && x < nx) {
-            const TIn* rrow = ref + (int64_t)y * nx + x;
-            const TIn* mrow = img + (int64_t)(ny - 1 - y) * nx + (nx - 1 - x);     // pixel x, then x+1 at -1, ...
-            TIn ri[4] = {0, 0, 0, 0}, mi[4] = {0, 0, 0, 0};
-            if (x + 3 < nx) {
-                const Quad<TIn> r = load_quad(rrow);
-                const Quad<TIn> t = load_quad(mrow - 3);
+    for (int half = 0; half < 2; ++half) {
+        ChunkLoad<TIn> top[4], bot[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { ri[e] = r.v[e]; mi[e] = t.v[3 - e]; }
-            } else {
-                for (int e = 0; e < 4 && x + e < nx; ++e) { ri[e] = rrow[e]; mi[e] = mrow[-e]; }
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + (4 * half + i) * kThreads;
+            const int yl = idx >> 5, x = (idx & 31) << 2;
+            top[i] = chunk_issue(ref, img, ny, nx, yl, x);
+            bot[i] = chunk_issue(ref, img, ny, nx, yl + 64, x);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + (4 * half + i) * kThreads;
+            const int yl = idx >> 5, x = (idx & 31) << 2;
+            float tre[4], tim[4], bre[4], bim[4];
+            chunk_unpack(top[i], ns, tre, tim);
+            chunk_unpack(bot[i], ns, bre, bim);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {        // sums of squares of the staged pixels (balance factor)
+                ssq[0] += tre[e] * tre[e] + bre[e] * bre[e];
+                ssq[1] += tim[e] * tim[e] + bim[e] * bim[e];
             }
-            const int nin = nx - x < 4 ? nx - x : 4;          // pixels of the chunk inside the cutout
+            f32x4 ore, oim;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (ns.active && e < nin) {
-                    mm[e] = norm_im(mi[e], ns);
-                    rr[e] = norm_ref(ri[e], ns);
-                } else {
-                    mm[e] = (float)mi[e];
-                    rr[e] = (float)ri[e];
-                }
-                mm[e] *= bal;
+                // top + w * bottom (w = 1: exact sums); the image carries the balance factor
+                const float ti = bal * tim[e], bi = bal * bim[e];
+                ore[e] = __builtin_fmaf(-wi, bi, __builtin_fmaf(wr, bre[e], tre[e]));
+                oim[e] = __builtin_fmaf(wi, bre[e], __builtin_fmaf(wr, bi, ti));
             }
+            *reinterpret_cast<f32x4*>(ure + yl * kUS + x) = ore;
+            *reinterpret_cast<f32x4*>(uim + yl * kUS + x) = oim;
         }
-        *reinterpret_cast<f32x4*>(zre + yl * L::ZS + (x4 << 2)) = f32x4{rr[0], rr[1], rr[2], rr[3]};
-        *reinterpret_cast<f32x4*>(zim + yl * L::ZS + (x4 << 2)) = f32x4{mm[0], mm[1], mm[2], mm[3]};
     }
 }
 
-// sum ref^2 and sum img^2 over the cutout (after normalisation) -> balance factor.
-// Latency-bound (2 workgroups/CU): 16-byte loads, 16 of them in flight per thread.
-template <typename TIn>
-SPX_DEVICE float balance128(unsigned char* scr, const TIn* __restrict__ ref,
-                            const TIn* __restrict__ img, int ny, int nx, const NormStatsT<TIn>& ns) {
-    const int tid = fresh_tid();
-    float ssq[2] = {0.0f, 0.0f};
-    const int npx = ny * nx;
-    const bool vec = (npx & 3) == 0 &&
-                     ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(img)) & 15) == 0;
-    auto add = [&](TIn ri, TIn mi) {
-        float r = (float)ri, m = (float)mi;
-        if (ns.active) {
-            m = norm_im(mi, ns);
-            r = norm_ref(ri, ns);
-        }
-        ssq[0] += r * r;
-        ssq[1] += m * m;
-    };
-    if (vec) {
-        const int n4 = npx >> 2;
-        constexpr int UN = sizeof(TIn) == 4 ? 8 : 4;      // 16 loads of 16 bytes in flight per thread
-        for (int base = 0; base < n4; base += UN * kThreads) {
-            Quad<TIn> r[UN], m[UN];
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int i = base + u * kThreads + tid;
-                r[u] = i < n4 ? load_quad(ref + 4 * (int64_t)i) : Quad<TIn>{{0, 0, 0, 0}};
-                m[u] = i < n4 ? load_quad(img + 4 * (int64_t)i) : Quad<TIn>{{0, 0, 0, 0}};
-            }
-#pragma unroll
-            for (int u = 0; u < UN; ++u)
-                if (base + u * kThreads + tid < n4) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) add(r[u].v[e], m[u].v[e]);
-                }
-        }
-    } else {
-#pragma unroll 8
-        for (int i = tid; i < npx; i += kThreads) add(ref[i], img[i]);
-    }
-    return balance_factor(scr, ssq);
-}
-
-// One round: classes (cy, cx = wave) of the staged pair -> complex planes in the workspace.
+// Round 0 (cy = 0) also finds the balance factor: its fold along y has w = 1, so the slab keeps
+// ref and image apart (real plane = ref, imaginary plane = image) and the factor -- known only
+// once the whole pair has been staged -- is applied when the waves read the slab; the later
+// rounds stage with it.  No separate pass over the pair for the sums of squares.
 template <int C, int DBG, typename TIn>
 SPX_DEVICE void class_round128(unsigned char* lds, const TIn* __restrict__ ref,
                                const TIn* __restrict__ img, int ny, int nx, const NormStatsT<TIn>& ns,
-                               float bal, int cy, float* __restrict__ ws, PhaseClock<DBG>& clk) {
+                               float& bal, int cy, float* __restrict__ ws, PhaseClock<DBG>& clk) {
     typedef LdsBig<C> L;
     static_assert(C == 3 || C == 4, "");
     const int tid = fresh_tid();
@@ -162,54 +131,38 @@ SPX_DEVICE void class_round128(unsigned char* lds, const TIn* __restrict__ ref,
     const int l1 = lane >> 3, l0 = lane & 7;
     const cf* tw = reinterpret_cast<const cf*>(lds + L::TW_OFF);
     const float* zre = reinterpret_cast<const float*>(lds + L::R_OFF);
-    const float* zim = zre + 64 * L::ZS;
     float* xch = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::XCH_WAVE_BYTES);
 
     rt::block_sync_lds();      // the previous round's exchange buffers alias the staging area
-    cf v[8][8];
-#pragma unroll
-    for (int r = 0; r < 64; ++r) v[r >> 3][r & 7] = cf{0.0f, 0.0f};
-    // fold the four quadrant blocks: v += (-i)^(cy sy + cx sx) z[y'+64 sy][x'+64 sx]
-    for (int s = 0; s < 4; ++s) {
-        const int sy = s >> 1, sx = s & 1;
-        const bool any = (64 * sy < ny) && (64 * sx < nx);      // block not entirely padding
-        if (any) stage_block128(lds, ref, img, ny, nx, sy, sx, ns, bal);
-        rt::block_sync_lds();
-        if (any) {
-            // d += w_C^m t,  w_C = exp(-2 pi i / C),  m = cy sy + cx sx
-            if constexpr (C == 4) {
-                // rotations by -i: the compiler turns this element-wise case split into
-                // compact code by itself (and spills if it is split by hand)
-                const int m = (cy * sy + cx * sx) & 3;
-#pragma unroll
-                for (int y1 = 0; y1 < 8; ++y1)
-#pragma unroll
-                    for (int x1 = 0; x1 < 8; ++x1) {
-                        const int a = (l1 + 8 * y1) * L::ZS + l0 + 8 * x1;
-                        const cf t = cf{zre[a], zim[a]};
-                        cf& d = v[y1][x1];
-                        if (m == 0) d = d + t;
-                        else if (m == 1) d = rt::add_mi(d, t);
-                        else if (m == 2) d = d - t;
-                        else d = rt::add_pi(d, t);
-                    }
-            } else {
-                // one branch-free path: d += w t with w = 1, w_3 or w_3^2 (the products with
-                // w = 1 are exact), so the register tile never passes a control-flow join
-                const int m = (cy * sy + cx * sx) % C;
-                const cf w = cf{m == 0 ? 1.0f : -0.5f,
-                                m == 0 ? 0.0f : (m == 1 ? -0.86602540378443865f : 0.86602540378443865f)};
-#pragma unroll
-                for (int y1 = 0; y1 < 8; ++y1)
-#pragma unroll
-                    for (int x1 = 0; x1 < 8; ++x1) {
-                        const int a = (l1 + 8 * y1) * L::ZS + l0 + 8 * x1;
-                        rt::cmac_ip(v[y1][x1], cf{zre[a], zim[a]}, w);
-                    }
-            }
-        }
+    float ssq[2] = {0.0f, 0.0f};
+    stage_yfold<C, TIn>(lds, ref, img, ny, nx, ns, cy == 0 ? 1.0f : bal, cy, ssq);
+    float ib = 1.0f;           // factor still to be applied to the imaginary plane
+    if (cy == 0) {
+        bal = balance_factor(lds + L::SCR_OFF, ssq);      // includes the barrier after staging
+        ib = bal;
+    } else {
         rt::block_sync_lds();
     }
+    // fold along x: v = u[y][x'] + w_C^cx u[y][x'+64]
+    cf v[8][8];
+    {
+        const float* ure = zre;
+        const float* uim = zre + 64 * kUS;
+        const cf w = cf{cx == 0 ? 1.0f : (C == 4 ? (cx == 2 ? -1.0f : 0.0f) : -0.5f),
+                        cx == 0 ? 0.0f : (C == 4 ? (cx == 1 ? -1.0f : (cx == 3 ? 1.0f : 0.0f))
+                                                 : (cx == 1 ? -0.86602540378443865f : 0.86602540378443865f))};
+        const bool two = nx > 64;                 // the right half is all padding otherwise
+#pragma unroll
+        for (int y1 = 0; y1 < 8; ++y1)
+#pragma unroll
+            for (int x1 = 0; x1 < 8; ++x1) {
+                const int a = (l1 + 8 * y1) * kUS + l0 + 8 * x1;
+                cf d = cf{ure[a], ib * uim[a]};
+                if (two) rt::cmac_ip(d, cf{ure[a + 64], ib * uim[a + 64]}, w);
+                v[y1][x1] = d;
+            }
+    }
+    rt::block_sync_lds();      // every wave has read the slab before any transposition overwrites it
     clk.tick(1);
     // class pre-twiddle w_P^{c (8 y1)}
     if (cy) {
@@ -318,10 +271,22 @@ template <int C> SPX_DEVICE void class_dft(const cf (&a)[C], cf (&x)[C]) {
 
 // radix-C combination of the C*C class planes into the full real convolution:
 // conv[l'+64 s] = out_scale * Im( sum_c conj(w_C)^(cy sy + cx sx) g_c[l'] )
-template <int C>
-SPX_DEVICE void combine128(const float* __restrict__ ws, float* __restrict__ conv, float out_scale) {
+// fused with what the caller needs from the flipped 'same' window (rows [loy, loy+ny) x columns
+// [lox, lox+nx) of the convolution; q = (n-1) + lo - l, conv_index inverted):
+//   MODE 0 (pair mode):      the full convolution goes to `conv` (the refine stage reads all of it)
+//                            and (bv, bi) take this thread's arg-max over the window, index qy*nx+qx;
+//   MODE 1 (reference mode): the window goes straight to its interlaced positions
+//                            icc[2 qy + oy][2 qx + ox] (cc.py:121-126), nothing else is stored, and
+//                            (bv, bi) ACCUMULATE the arg-max over the interlaced image (NaN ranked
+//                            as +inf, see nan_as_inf).
+template <int C, int MODE>
+SPX_DEVICE void combine128(const float* __restrict__ ws, float* __restrict__ conv, float out_scale,
+                           int ny, int nx, float* __restrict__ icc, int ox, int oy, float& bv, int& bi) {
     typedef LdsBig<C> L;
     const int tid = fresh_tid();
+    const int loy = (ny - 1) / 2, lox = (nx - 1) / 2;
+    const int NX2 = 2 * nx;
+#pragma unroll 2
     for (int i4 = tid; i4 < 64 * 64 / 4; i4 += kThreads) {          // 4 consecutive l'x per step
         f32x4 gre[C * C], gim[C * C];
 #pragma unroll
@@ -352,30 +317,52 @@ SPX_DEVICE void combine128(const float* __restrict__ ws, float* __restrict__ con
             }
         }
 #pragma unroll
-        for (int sy = 0; sy < C; ++sy)
+        for (int sy = 0; sy < C; ++sy) {
+            const int qy = (ny - 1) + loy - (ly + 64 * sy);
+            const bool rowin = qy >= 0 && qy < ny;
 #pragma unroll
             for (int sx = 0; sx < C; ++sx) {
-                float* row = conv + (size_t)(ly + 64 * sy) * L::CS;
-                *reinterpret_cast<f32x4*>(row + lx + 64 * sx) = o[sy][sx];
-                if (sx == 0 && lx == 0) *reinterpret_cast<f32x4*>(row + L::P) = o[sy][sx];   // wrap copy
+                if constexpr (MODE == 0) {
+                    float* row = conv + (size_t)(ly + 64 * sy) * L::CS;
+                    *reinterpret_cast<f32x4*>(row + lx + 64 * sx) = o[sy][sx];
+                    if (sx == 0 && lx == 0) *reinterpret_cast<f32x4*>(row + L::P) = o[sy][sx];   // wrap copy
+                }
+                if (rowin) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int qx = (nx - 1) + lox - (lx + e + 64 * sx);
+                        if (qx >= 0 && qx < nx) {
+                            if constexpr (MODE == 0) {
+                                const int idx = qy * nx + qx;
+                                if (better(o[sy][sx][e], idx, bv, bi)) { bv = o[sy][sx][e]; bi = idx; }
+                            } else {
+                                const int gi = (2 * qy + oy) * NX2 + 2 * qx + ox;
+                                const float val = o[sy][sx][e];
+                                icc[gi] = val;
+                                if (better(nan_as_inf(val), gi, bv, bi)) { bv = nan_as_inf(val); bi = gi; }
+                            }
+                        }
+                    }
+                }
             }
+        }
     }
 }
 
-// cutout pair -> full PxP convolution in the workspace (ends with a full barrier)
-template <int C, int DBG, typename TIn>
+// cutout pair -> class planes -> combine (ends with a full barrier).  MODE as in combine128.
+template <int C, int DBG, typename TIn, int MODE>
 SPX_DEVICE void conv_full128(unsigned char* lds, const TIn* __restrict__ ref,
                              const TIn* __restrict__ img, int ny, int nx, const NormStatsT<TIn>& ns,
-                             float* __restrict__ ws, PhaseClock<DBG>& clk) {
+                             float* __restrict__ ws, PhaseClock<DBG>& clk, float* __restrict__ icc,
+                             int ox, int oy, float& bv, int& bi) {
     typedef LdsBig<C> L;
-    unsigned char* scr = lds + L::SCR_OFF;
-    const float bal = balance128(scr, ref, img, ny, nx, ns);
+    float bal = 1.0f;                    // set by round 0
     clk.tick(0);
     for (int cy = 0; cy < C; ++cy) class_round128<C, DBG, TIn>(lds, ref, img, ny, nx, ns, bal, cy, ws, clk);
     rt::block_sync();                    // class planes (global) visible to every wave
     // conv = Im(IFFT(Z^2)) / 2, IFFT normalisation 1/P^2, balance undone
     const float out_scale = 0.5f / ((float)(L::P) * (float)(L::P) * bal);
-    combine128<C>(ws, ws + L::kConvOffsetFloats, out_scale);
+    combine128<C, MODE>(ws, ws + L::kConvOffsetFloats, out_scale, ny, nx, icc, ox, oy, bv, bi);
     rt::block_sync();
     clk.tick(4);
 }
@@ -385,84 +372,58 @@ SPX_DEVICE float window_value128(const float* __restrict__ conv, int ny, int nx,
     return conv[(size_t)conv_index(ny, qy) * LdsBig<C>::CS + conv_index(nx, qx)];
 }
 
-// coarse arg-max over the flipped 'same' window (cutouts up to 128x128): the window is rows
-// [loy, loy+ny) x columns [lox, lox+nx) of the convolution, walked in storage order with
-// 16-byte loads; q = (n-1) + lo - l (conv_index inverted).
-template <int C>
-SPX_DEVICE void coarse_argmax128(const float* __restrict__ conv, int ny, int nx, float& bv, int& bi) {
-    const int tid = fresh_tid();
-    bv = -__builtin_inff();
-    bi = 0x7fffffff;
-    const int loy = (ny - 1) / 2, lox = (nx - 1) / 2;
-    const int c4lo = lox >> 2;                               // first aligned column chunk
-    const int nchunk = ((lox + nx - 1) >> 2) - c4lo + 1;     // chunks per row (<= 33)
-    const int total = ny * nchunk;
-#pragma unroll 8
-    for (int g = tid; g < total; g += kThreads) {
-        const int ry = g / nchunk, ch = g - ry * nchunk;
-        const int ly = loy + ry, lx4 = (c4lo + ch) << 2;
-        const f32x4 d = *reinterpret_cast<const f32x4*>(conv + (size_t)ly * LdsBig<C>::CS + lx4);
-        const int qy = (ny - 1) + loy - ly;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int qx = (nx - 1) + lox - (lx4 + e);
-            const int idx = qy * nx + qx;
-            if (qx >= 0 && qx < nx && better(d[e], idx, bv, bi)) { bv = d[e]; bi = idx; }
-        }
-    }
-}
-
 // Fine window around flipped coarse index (qyc, qxc) by MFMA, period-P real kernel
 //   K(t) = 1/P [1 + 2 sum_{j=1..P/2-1} cos(2 pi j t / P) + cos(pi t)].
-// Wave w < C contracts all P rows for the 64 window columns mx'' in [64 w - P/2, 64 w - P/2 + 64)
-// and leaves its partial window in its own LDS buffer; the reader adds the four (fine_value128;
-// for C = 3 the fourth wave leaves zeros).  Inside the wave, A-row lj of column tile t is column
-// 64 w + 4 lj + t, so that a lane's four tiles are 4 consecutive columns = ONE 16-byte load per
-// row (P/4 per lane instead of P 4-byte ones); accumulator register r of tile t is then column
-// 64 w + 16 lk + 4 r + t.  Tables (spx_tables.h make_ktab_big), lane = 16 lk + lj:
+// Each of the four waves contracts all P rows for CW = P/4 window columns mx'' in
+// [CW w - P/2, CW w - P/2 + CW) (TPW = CW/16 column tiles: 3 for P = 192, 4 for P = 256) and
+// leaves its partial window in its own LDS buffer; the reader adds the four (fine_value128).
+// Inside the wave, A-row lj of column tile t is column CW w + TPW lj + t, so that a lane's tiles
+// are TPW consecutive columns = ONE 12- or 16-byte load per row; accumulator register r of tile t
+// is then column CW w + 4 TPW lk + TPW r + t.  Tables (spx_tables.h make_ktab_big), lane = 16 lk + lj:
 //   [0][blk][lane][s]       = K(-(16 blk + lj - W/2)/U - (4 s + lk - P/2)),       s in [0, P/4)
-//   [1][blk][lane][4 T + r] = K(-(16 blk + lj - W/2)/U - (64 w + 16 lk + 4 r + t - P/2)), T = 4 w + t
+//   [1][blk][lane][4 T + r] = K(-(16 blk + lj - W/2)/U - (CW w + 4 TPW lk + TPW r + t - P/2)), T = TPW w + t
+template <int TPW> struct __attribute__((packed, aligned(4))) RowFrag { float v[TPW]; };
 template <int C, int WB>
 SPX_DEVICE void fine_window128(unsigned char* lds, const float* __restrict__ ktab,
                                const float* __restrict__ conv, int ny, int nx, int qyc, int qxc) {
     typedef LdsBig<C> L;
     constexpr int W = 16 * WB;
     constexpr int NQ = L::P / 16;            // 16-byte table entries per (block, lane)
+    constexpr int CW = L::P / 4;             // window columns per wave
+    constexpr int TPW = CW / 16;             // column tiles per wave
     const int tid = fresh_tid();
     const int wave = tid >> 6, lane = tid & 63;
     const int lk = lane >> 4, lj = lane & 15;
     float* fbuf = reinterpret_cast<float*>(lds + L::FB_OFF) + wave * W * W;
-    if (wave >= C) {                         // C = 3: nothing to contract, contribute zeros
-        for (int i = lane; i < W * W; i += 64) fbuf[i] = 0.0f;
-        rt::block_sync_lds();
-        return;
-    }
+    // (window centre clamped into the cutout: a corrupted index must not become an address)
+    qyc = qyc < 0 ? 0 : (qyc > ny - 1 ? ny - 1 : qyc);
+    qxc = qxc < 0 ? 0 : (qxc > nx - 1 ? nx - 1 : qxc);
     const int lyc = conv_index(ny, qyc), lxc = conv_index(nx, qxc);
     ktab = rt::launder(ktab);
     const f32x4* kty = reinterpret_cast<const f32x4*>(ktab) + (size_t)lane * NQ;
     const f32x4* ktx = reinterpret_cast<const f32x4*>(ktab) + (size_t)(WB * 64 + lane) * NQ;
 
-    f32x4 acc[WB][4];
+    f32x4 acc[WB][TPW];
 #pragma unroll
     for (int ab = 0; ab < WB; ++ab)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[ab][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int col0 = L::wrap(lxc + 64 * wave + 4 * lj - L::P / 2);     // + t, t = 0..3 (wrap copy in the row)
+        for (int t = 0; t < TPW; ++t) acc[ab][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int col0 = L::wrap(lxc + CW * wave + TPW * lj - L::P / 2);     // + t (wrap copy in the row)
 #pragma unroll 4
     for (int s4 = 0; s4 < NQ; ++s4) {
         f32x4 kb[WB];
 #pragma unroll
         for (int ab = 0; ab < WB; ++ab) kb[ab] = kty[(size_t)ab * 64 * NQ + s4];
-        F32x4U a4[4];
+        RowFrag<TPW> a4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int row = L::wrap(lyc + 4 * (4 * s4 + e) + lk - L::P / 2);
-            a4[e] = *reinterpret_cast<const F32x4U*>(conv + (size_t)row * L::CS + col0);
+            a4[e] = *reinterpret_cast<const RowFrag<TPW>*>(conv + (size_t)row * L::CS + col0);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < TPW; ++t)
 #pragma unroll
                 for (int ab = 0; ab < WB; ++ab)
                     acc[ab][t] = rt::mfma_16x16x4(a4[e].v[t], kb[ab][e], acc[ab][t]);
@@ -473,10 +434,10 @@ SPX_DEVICE void fine_window128(unsigned char* lds, const float* __restrict__ kta
 #pragma unroll
         for (int ab = 0; ab < WB; ++ab) f[bb][ab] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < TPW; ++t) {
         f32x4 ka[WB];
 #pragma unroll
-        for (int bb = 0; bb < WB; ++bb) ka[bb] = ktx[(size_t)bb * 64 * NQ + 4 * wave + t];
+        for (int bb = 0; bb < WB; ++bb) ka[bb] = ktx[(size_t)bb * 64 * NQ + TPW * wave + t];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -518,12 +479,11 @@ SPX_DEVICE void pair128_body(const TIn* __restrict__ ref, const TIn* __restrict_
     const int tid = fresh_tid();
     unsigned char* scr = lds + L::SCR_OFF;
     const NormStatsT<TIn> ns = norm_stats(scr, ref, img, 1, 0, ny, nx, cc_type);
-    conv_full128<C, DBG, TIn>(lds, ref, img, ny, nx, ns, ws, clk);
+    // coarse arg-max over the flipped 'same' window: found by the combine pass itself
+    float bv = -__builtin_inff();
+    int bi = kNoIndex;
+    conv_full128<C, DBG, TIn, 0>(lds, ref, img, ny, nx, ns, ws, clk, nullptr, 0, 0, bv, bi);
     const float* conv = ws + L::kConvOffsetFloats;
-
-    float bv;
-    int bi;
-    coarse_argmax128<C>(conv, ny, nx, bv, bi);
     block_argmax(scr, bv, bi, 0);
     const bool nonfinite = bi == kNoIndex;       // NaN everywhere (see pair_body in spx_kernels.h)
     if (nonfinite) bi = 0;
@@ -636,7 +596,6 @@ SPX_TKERNEL(256) void disp5_128_kernel(const TIn* __restrict__ ref, const TIn* _
     SPX_DYN_LDS(lds);
     load_twiddles128<C>(lds, tw_g);
     float* ws = workspace + (size_t)rt::block_id() * (L::kWsBytes / sizeof(float));
-    const float* conv = ws + L::kConvOffsetFloats;
     unsigned char* scr = lds + L::SCR_OFF;
     const int64_t stride = (int64_t)ny * nx;
     const int NX = 2 * nx, NY = 2 * ny;
@@ -651,17 +610,8 @@ SPX_TKERNEL(256) void disp5_128_kernel(const TIn* __restrict__ ref, const TIn* _
         PhaseClock<0> clk;
         for (int q = 0; q < 4; ++q) {
             const int ox = q & 1, oy = q >> 1;
-            conv_full128<C, 0, TIn>(lds, r, m4 + q * stride, ny, nx, ns, ws, clk);
-            const int qx = tid & 127;
-            if (qx < nx) {
-                for (int qy = tid >> 7; qy < ny; qy += kThreads / 128) {
-                    const float val = window_value128<C>(conv, ny, nx, qy, qx);
-                    const int gi = (2 * qy + oy) * NX + 2 * qx + ox;
-                    icc[gi] = val;
-                    if (better(nan_as_inf(val), gi, bv, bi)) { bv = nan_as_inf(val); bi = gi; }
-                }
-            }
-            rt::block_sync();
+            // the combine pass writes this dither's window straight into the interlaced image
+            conv_full128<C, 0, TIn, 1>(lds, r, m4 + q * stride, ny, nx, ns, ws, clk, icc, ox, oy, bv, bi);
         }
         block_argmax(scr, bv, bi, 0);
         const bool nonfinite = !(bv < __builtin_inff());        // see disp5_body (spx_kernels.h)

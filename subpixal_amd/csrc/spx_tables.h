@@ -92,7 +92,8 @@ inline std::vector<float> make_ktab32(int U, int W) {
 // Period-256 real interpolation kernel (128 tile) and its lane-major MFMA tables
 // (spx_kernels128.h fine_window128), P = 192 or 256:
 //   [0][blk][lane][s]       = K(-(16 blk + lj - W/2)/U - (4 s + lk - P/2)),        s in [0,P/4)
-//   [1][blk][lane][4 T + r] = K(-(16 blk + lj - W/2)/U - (64 w + 16 lk + 4 r + t - P/2)), T = 4 w + t
+//   [1][blk][lane][4 T + r] = K(-(16 blk + lj - W/2)/U - (CW w + 4 TPW lk + TPW r + t - P/2)),
+//                             CW = P/4 columns per wave, TPW = CW/16 column tiles, T = TPW w + t
 inline double kernel_big(int P, double t) {
     double s = 1.0 + std::cos(kPi * t);
     for (int k = 1; k < P / 2; ++k) s += 2.0 * std::cos(2.0 * kPi * k * t / (double)P);
@@ -107,9 +108,11 @@ inline std::vector<float> make_ktab_big(int P, int U, int W) {
             for (int lane = 0; lane < 64; ++lane)
                 for (int i = 0; i < n; ++i) {
                     const int lk = lane >> 4, lj = lane & 15;
-                    // [1]: i = 4 T + r, T = 4 w + t  ->  column 64 w + 16 lk + 4 r + t
+                    // [1]: i = 4 T + r, T = TPW w + t  ->  column CW w + 4 TPW lk + TPW r + t
+                    const int cw = P / 4, tpw = cw / 16;
+                    const int T = i >> 2, r = i & 3, w = T / tpw, tt = T % tpw;
                     const int m = which == 0 ? (4 * i + lk - P / 2)
-                                             : (64 * (i >> 4) + 16 * lk + 4 * (i & 3) + ((i >> 2) & 3) - P / 2);
+                                             : (cw * w + 4 * tpw * lk + tpw * r + tt - P / 2);
                     const double t = -(double)(16 * blk + lj - W / 2) / (double)U - (double)m;
                     k[(((size_t)which * blocks + blk) * 64 + lane) * n + i] = (float)kernel_big(P, t);
                 }

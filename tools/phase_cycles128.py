@@ -26,8 +26,8 @@ out = torch.zeros((N, 2), dtype=torch.float64, device='cuda')
 st = torch.zeros((N + 64,), dtype=torch.int32, device='cuda')
 nws = lib.spx_workspace_bytes_xcorr(N, 128, 128)
 ws = torch.empty((nws,), dtype=torch.uint8, device='cuda')
-names = ['norm + balance', 'stage + fold (4 blocks, 9 barriers)', 'class FFTs', 'class planes -> workspace',
-         'sync + combine + sync', 'coarse argmax', 'fine window MFMA', 'fine argmax', 'fit + store', 'end barrier']
+names = ['norm + balance', 'stage y-fold + x-fold (3 rounds)', 'class FFTs', 'class planes -> workspace',
+         'sync + combine + arg-max + sync', 'block arg-max', 'fine window MFMA', 'fine argmax', 'fit + store', 'end barrier']
 
 
 def run():
