@@ -26,6 +26,8 @@
  *                                   affine over a cutout; drizzlepac is not in the reference
  *                                   tree, the quintic is restated from the published (IRAF
  *                                   bipoly5 / Everett) formula: parity UNPINNED.
+ *   spx_blot_poly4_f32          <-  the same four blots through a distorted (polynomial, degree
+ *                                   <= 5) coordinate map: BlotWCSMap, blot.py:21-76.
  *   spx_gen_gaussian_pairs_f32  --  synthetic workload generator (bench / tests only).
  *
  * Conventions
@@ -201,6 +203,20 @@ int spx_label_bboxes_i32(const int32_t* seg, int fny, int fnx, int32_t max_label
  */
 int spx_blot_affine4_f32(const float* src, int64_t nbatch, int sny, int snx, const double* affine,
                          const float* gain, int ny, int nx, float* im4, void* stream);
+
+/*
+ * The same four blots through a map that is NOT affine over the cutout (instrument distortion:
+ * what the reference's BlotWCSMap evaluates per pixel, blot.py:21-76): per source a bivariate
+ * polynomial of total degree `degree` (1..5) in the target position relative to the cutout centre,
+ *   u = x + ox - (nx-1)/2,  v = y + oy - (ny-1)/2,
+ *   xs = sum_{d=0..degree} sum_{i=d..0} coef[b][0][k] u^i v^(d-i),  k = d(d+1)/2 + (d-i),
+ *   ys likewise with coef[b][1][k];
+ *   coef : float64 [nbatch][2][21] (21 slots per axis whatever the degree; unused ones ignored).
+ * subpixal_amd.blot.poly_from_map fits the coefficients from any callable map and reports the
+ * residual; everything else as spx_blot_affine4_f32.  Parity with drizzlepac: UNPINNED.
+ */
+int spx_blot_poly4_f32(const float* src, int64_t nbatch, int sny, int snx, const double* coef,
+                       int degree, const float* gain, int ny, int nx, float* im4, void* stream);
 
 /*
  * Synthetic Gaussian-spot pairs: pair k = first_index + i has

@@ -39,7 +39,7 @@ __all__ = [
     'cross_power_spectrum', 'upsampled_cc', 'upsampled_cc_window',
     'xcorr_refine', 'xcorr_refine_batch', 'find_displacement_batch',
     'QUAD_PINV_5X5', 'STATUS_OK', 'STATUS_EDGE', 'STATUS_NOMAX',
-    'STATUS_OUTSIDE', 'STATUS_NONFINITE', 'primary_boxes', 'blot_affine4',
+    'STATUS_OUTSIDE', 'STATUS_NONFINITE', 'primary_boxes', 'blot_affine4', 'blot_map4',
 ]
 
 # per-item status codes shared with the HIP library (include/subpixal_hip.h)
@@ -647,24 +647,17 @@ def _continued(tile, j, i):
     return along_x(j, i)
 
 
-def blot_affine4(src, affine, ny, nx, gain=None):
-    """``im4 [N, 4, ny, nx]`` float64: dithers 00, 10, 01, 11 <-> (ox, oy) in {0, 1/2}^2;
-    ``imct.dx -= ox`` (align.py:668-676) puts cutout pixel x at image position x + blc - dx0 + ox
-    (cutout.py:1138), i.e. the dither samples target position (x + ox, y + oy);
-    target (x', y') -> source (a0 x' + a1 y' + a2, a3 x' + a4 y' + a5)."""
+def _blot4(src, maps, ny, nx, gain=None):
+    """``im4 [N, 4, ny, nx]`` float64 for per-source maps ``maps[b](xt, yt) -> (xs, ys)``."""
     src = np.asarray(src, dtype=np.float64)
-    affine = np.asarray(affine, dtype=np.float64)
     n, sny, snx = src.shape
     out = np.zeros((n, 4, ny, nx))
     for b in range(n):
-        a = affine[b]
         for q in range(4):
             ox, oy = 0.5 * (q & 1), 0.5 * ((q >> 1) & 1)
             for y in range(ny):
                 for x in range(nx):
-                    xt, yt = x + ox, y + oy
-                    xs = a[0] * xt + a[1] * yt + a[2]
-                    ys = a[3] * xt + a[4] * yt + a[5]
+                    xs, ys = maps[b](x + ox, y + oy)
                     if not (0.0 <= xs <= snx - 1 and 0.0 <= ys <= sny - 1):
                         continue
                     ix, iy = int(np.floor(xs)), int(np.floor(ys))
@@ -678,3 +671,22 @@ def blot_affine4(src, affine, ny, nx, gain=None):
         if gain is not None:
             out[b] *= float(gain[b])
     return out
+
+
+def blot_affine4(src, affine, ny, nx, gain=None):
+    """``im4 [N, 4, ny, nx]`` float64: dithers 00, 10, 01, 11 <-> (ox, oy) in {0, 1/2}^2;
+    ``imct.dx -= ox`` (align.py:668-676) puts cutout pixel x at image position x + blc - dx0 + ox
+    (cutout.py:1138), i.e. the dither samples target position (x + ox, y + oy);
+    target (x', y') -> source (a0 x' + a1 y' + a2, a3 x' + a4 y' + a5)."""
+    affine = np.asarray(affine, dtype=np.float64)
+
+    def mk(a):
+        return lambda xt, yt: (a[0] * xt + a[1] * yt + a[2], a[3] * xt + a[4] * yt + a[5])
+    return _blot4(src, [mk(a) for a in affine], ny, nx, gain)
+
+
+def blot_map4(src, mappings, ny, nx, gain=None):
+    """The same four blots through arbitrary per-source callables ``(xt, yt) -> (xs, ys)`` on the
+    0-based un-dithered target grid (what BlotWCSMap does per pixel, blot.py:71-76): the float64
+    reference the polynomial-map kernel ``spx_blot_poly4_f32`` is checked against."""
+    return _blot4(src, list(mappings), ny, nx, gain)

@@ -43,6 +43,8 @@ _SIGNATURES = {
     'spx_label_bboxes_i32': (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int32, _vp, _vp, _vp]),
     'spx_blot_affine4_f32': (_c.c_int, [_vp, _c.c_int64, _c.c_int, _c.c_int, _vp, _vp, _c.c_int,
                                         _c.c_int, _vp, _vp]),
+    'spx_blot_poly4_f32': (_c.c_int, [_vp, _c.c_int64, _c.c_int, _c.c_int, _vp, _c.c_int, _vp, _c.c_int,
+                                      _c.c_int, _vp, _vp]),
     'spx_gen_gaussian_pairs_f32': (_c.c_int, [_c.c_uint64, _c.c_int64, _c.c_int64, _c.c_int,
                                               _c.c_float, _c.c_float, _c.c_float, _vp, _vp,
                                               _vp, _vp]),

@@ -176,16 +176,18 @@ def _image_xy(ct, x, y, wcslin):
     return np.array([x + ct.blc[0] - ct.dx + 1.0, y + ct.blc[1] - ct.dy + 1.0])
 
 
-def measure_shifts_affine(img_tiles, drz_tiles, affine, gain=None, cc_type='NCC'):
+def measure_shifts_affine(img_tiles, drz_tiles, affine, gain=None, cc_type='NCC', degree=None):
     """The loop body of align.py:656-689 with the four blots made on the GPU
     (``blot.blot_affine4_batch``): ``img_tiles[k]`` and ``drz_tiles[k]`` are 2-D arrays,
-    ``affine[k]`` maps image-cutout pixels to drizzled-cutout pixels.  The blots never leave
-    the device.  Returns ``(dxdy [N, 2], interlaced images, non-shifted blots, status [N])``;
+    ``affine[k]`` maps image-cutout pixels to drizzled-cutout pixels (``[N, 6]``; with ``degree``
+    given it is the ``[N, 2, 21]`` polynomial coefficients of ``blot.poly_from_map`` instead and
+    ``blot.blot_poly4_batch`` does the resampling).  The blots never leave the device.  Returns ``(dxdy [N, 2], interlaced images, non-shifted blots, status [N])``;
     shapes the kernels do not take are skipped as in :func:`measure_shifts`."""
     import torch
     from . import blot as _blot
     n = len(img_tiles)
-    affine = np.asarray(affine, dtype=np.float64).reshape(n, 6)
+    affine = np.asarray(affine, dtype=np.float64)
+    affine = affine.reshape(n, 6) if degree is None else affine.reshape(n, 2, _blot.POLY_TERMS)
     gain = None if gain is None else np.asarray(gain, dtype=np.float32).reshape(n)
     dxdy = np.zeros((n, 2), dtype=np.float64)
     status = np.full(n, ST_SKIPPED, dtype=np.int32)
@@ -197,7 +199,9 @@ def measure_shifts_affine(img_tiles, drz_tiles, affine, gain=None, cc_type='NCC'
     for (ishape, _), idx in groups.items():
         ref = torch.as_tensor(np.stack([np.asarray(img_tiles[k], dtype=np.float32) for k in idx])).cuda()
         src = torch.as_tensor(np.stack([np.asarray(drz_tiles[k], dtype=np.float32) for k in idx])).cuda()
-        im4 = _blot.blot_affine4_batch(src, affine[idx], ishape, None if gain is None else gain[idx])
+        g = None if gain is None else gain[idx]
+        im4 = _blot.blot_affine4_batch(src, affine[idx], ishape, g) if degree is None else \
+            _blot.blot_poly4_batch(src, affine[idx], ishape, degree, g)
         d, icc, st = cc.find_displacement_batch(ref, im4, cc_type=cc_type, full_output=True,
                                                 return_status=True)
         d, icc, b0 = d.cpu().numpy(), icc.cpu().numpy(), im4[:, 0].cpu().numpy()
@@ -211,7 +215,7 @@ def measure_shifts_affine(img_tiles, drz_tiles, affine, gain=None, cc_type='NCC'
 
 def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
                     nclip=3, sigma=3.0, use_weights=True, cc_type='NCC', blot=None,
-                    affine=None, gain=None):
+                    affine=None, gain=None, poly=None):
     """Linear fit to the displacements (found by cross-correlation) between ``img_cutouts`` and
     the blots of ``drz_cutouts`` onto them.  Same arguments and return value
     ``(fit, interlaced_cc, nonshifted_blts)`` as the reference (align.py:561-745).
@@ -224,6 +228,8 @@ def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
         when given, ``drz_cutouts`` are the drizzled cutouts themselves and the four blots are
         resampled on the GPU (``blot.blot_affine4_batch``, quintic interpolation), with the optional
         per-source ``gain`` of blot.py:134-150.  ``blot`` must be None then.
+    poly : ``(coef [N, 2, 21], degree)`` polynomial maps (``blot.poly_from_map`` / ``blot.map_from``) for
+        cutouts over which instrument distortion makes the map non-affine; used like ``affine``.
     """
     if not hasattr(img_cutouts, '__iter__'):
         img_cutouts = [img_cutouts]
@@ -240,8 +246,11 @@ def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
     if wcslin is not None and hasattr(wcslin, 'deepcopy'):
         wcslin = wcslin.deepcopy()
 
-    if affine is not None and blot is not None:
-        raise ValueError("Give either a 'blot' callable or 'affine' maps, not both.")
+    if sum(x is not None for x in (affine, blot, poly)) > 1:
+        raise ValueError("Give either a 'blot' callable or 'affine' maps or 'poly' maps, not several.")
+    degree = None
+    if poly is not None:
+        affine, degree = poly
 
     def data_of(c):
         return c.data if hasattr(c, 'data') and not isinstance(c, np.ndarray) else np.asarray(c)
@@ -273,7 +282,7 @@ def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
     if affine is not None:
         img_dxy, interlaced_cc, nonshifted_blts, status = measure_shifts_affine(
             [data_of(c) for c in img_cutouts], [data_of(c) for c in drz_cutouts], affine, gain,
-            cc_type=cc_type)
+            cc_type=cc_type, degree=degree)
     else:
         img_dxy, interlaced_cc, status = measure_shifts(
             [data_of(c) for c in img_cutouts],

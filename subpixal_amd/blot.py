@@ -6,9 +6,11 @@ displaced by half a pixel (/root/reference/subpixal/align.py:664-676); each call
 drizzlepac's C ``tblot`` with ``interp='poly5'`` through a Python WCS callback
 (blot.py:79-155).  drizzlepac and the WCS stack are not part of the reference tree, so
 this module does NOT reproduce ``blot_cutout`` itself.  What it provides is the same
-resampling for coordinate maps that are *affine over one cutout* (a local linearisation
-of target-pixel -> source-pixel, excellent over <= 128 px), for all sources and all four
-dithers in one kernel launch: ``spx_blot_affine4_f32``.  The quintic interpolant is
+resampling for all sources and all four dithers in one kernel launch, for coordinate maps given
+per cutout either as an affine (``spx_blot_affine4_f32``: a local linearisation of target-pixel ->
+source-pixel) or, where instrument distortion makes the map non-affine at the 1e-3 px level, as a
+bivariate polynomial of degree <= 5 (``spx_blot_poly4_f32``); ``map_from`` picks the cheapest form
+that reproduces a callable map to a tolerance and refuses when none does.  The quintic interpolant is
 restated from its published form (IRAF bipoly5 / Everett's formula), see
 ``spx_aux_kernels.h``; parity with drizzlepac is unpinned.
 """
@@ -17,7 +19,10 @@ import torch
 
 from . import _ffi, device
 
-__all__ = ['blot_affine4_batch', 'affine_from_map', 'shift_affine']
+__all__ = ['blot_affine4_batch', 'blot_poly4_batch', 'affine_from_map', 'poly_from_map', 'map_from',
+           'shift_affine', 'POLY_TERMS']
+
+POLY_TERMS = 21          # monomials u^i v^j with i + j <= 5
 
 
 def shift_affine(count, x0=0.0, y0=0.0, scale=1.0):
@@ -50,6 +55,94 @@ def affine_from_map(mapping, shape):
     cy, *_ = np.linalg.lstsq(design, np.asarray(ys, dtype=np.float64), rcond=None)
     res = np.hypot(design @ cx - xs, design @ cy - ys).max()
     return np.concatenate([cx, cy]), float(res)
+
+
+def _poly_design(u, v, degree):
+    """Columns u^i v^(d-i) in the kernel's order: k = d(d+1)/2 + (d - i), d = 0..degree."""
+    cols = []
+    for d in range(degree + 1):
+        for i in range(d, -1, -1):
+            cols.append(u ** i * v ** (d - i))
+    return np.stack(cols, axis=1)
+
+
+def poly_from_map(mapping, shape, degree=3):
+    """Least-squares bivariate polynomial of a coordinate map over one target cutout, for maps
+    that are NOT affine over it (HST FLT distortion is not, at the 1e-3 px level, over 64-128 px):
+    what the reference's ``BlotWCSMap`` evaluates per pixel (blot.py:21-76).
+
+    mapping, shape : as :func:`affine_from_map`.
+    degree : total degree 1..5.
+    Returns ``(coef[2, 21], max_residual_px)``; the polynomial is in ``u = x - (nx-1)/2``,
+    ``v = y - (ny-1)/2`` (``spx_blot_poly4_f32``), the residual is taken over a 13x13 probe grid
+    (the fit uses a 9x9 one) INCLUDING the half-pixel dithered positions' range.
+    """
+    degree = int(degree)
+    if not 1 <= degree <= 5:
+        raise ValueError("degree must be 1..5")
+    ny, nx = int(shape[0]), int(shape[1])
+    xc, yc = 0.5 * (nx - 1), 0.5 * (ny - 1)
+
+    def grid(k):
+        gx, gy = np.meshgrid(np.linspace(0.0, nx - 0.5, k), np.linspace(0.0, ny - 0.5, k))
+        return gx.ravel(), gy.ravel()
+    gx, gy = grid(9)
+    xs, ys = mapping(gx, gy)
+    design = _poly_design(gx - xc, gy - yc, degree)
+    cx, *_ = np.linalg.lstsq(design, np.asarray(xs, dtype=np.float64), rcond=None)
+    cy, *_ = np.linalg.lstsq(design, np.asarray(ys, dtype=np.float64), rcond=None)
+    px, py = grid(13)
+    pxs, pys = mapping(px, py)
+    pd = _poly_design(px - xc, py - yc, degree)
+    res = np.hypot(pd @ cx - pxs, pd @ cy - pys).max()
+    coef = np.zeros((2, POLY_TERMS))
+    coef[0, :len(cx)] = cx
+    coef[1, :len(cy)] = cy
+    return coef, float(res)
+
+
+def map_from(mapping, shape, tol=1e-3):
+    """The cheapest map form that reproduces ``mapping`` over the cutout to ``tol`` pixels:
+    ``('affine', a[6], residual)`` or ``('poly', (coef[2, 21], degree), residual)`` with the lowest
+    sufficient degree.  Raises ValueError when even degree 5 leaves a larger residual (the blot
+    would be displaced by more than ``tol``: refuse rather than resample wrongly)."""
+    a, res = affine_from_map(mapping, shape)
+    if res <= tol:
+        return 'affine', a, res
+    for degree in (2, 3, 4, 5):
+        coef, res = poly_from_map(mapping, shape, degree)
+        if res <= tol:
+            return 'poly', (coef, degree), res
+    raise ValueError("coordinate map is not a degree-5 polynomial over the cutout to %g px "
+                     "(residual %.3g px)" % (tol, res))
+
+
+def blot_poly4_batch(src, coef, shape, degree, gain=None):
+    """The four dithered blots of every source through a polynomial coordinate map
+    (``spx_blot_poly4_f32``): ``coef [N, 2, 21]`` float64 as :func:`poly_from_map` returns them,
+    everything else as :func:`blot_affine4_batch`."""
+    like_torch = isinstance(src, torch.Tensor)
+    s = device.to_device(src, torch.float32)
+    if s.dim() != 3:
+        raise ValueError("src must have shape [N, sny, snx].")
+    c = device.to_device(np.asarray(coef, dtype=np.float64) if not isinstance(coef, torch.Tensor)
+                         else coef, torch.float64)
+    if c.dim() != 3 or tuple(c.shape[1:]) != (2, POLY_TERMS) or c.shape[0] != s.shape[0]:
+        raise ValueError("coef must have shape [N, 2, 21].")
+    g = None
+    if gain is not None:
+        g = device.to_device(np.asarray(gain, dtype=np.float32) if not isinstance(gain, torch.Tensor)
+                             else gain, torch.float32)
+        if g.dim() != 1 or g.shape[0] != s.shape[0]:
+            raise ValueError("gain must have shape [N].")
+    ny, nx = int(shape[0]), int(shape[1])
+    im4 = torch.empty((s.shape[0], 4, ny, nx), dtype=torch.float32, device=s.device)
+    lib = _ffi.load()
+    with torch.cuda.device(s.device):
+        _ffi.check(lib.spx_blot_poly4_f32(device.ptr(s), s.shape[0], s.shape[1], s.shape[2],
+                                          device.ptr(c), int(degree), device.ptr(g), ny, nx,
+                                          device.ptr(im4), device.stream_ptr()))
+    return im4 if like_torch else im4.cpu().numpy()
 
 
 def blot_affine4_batch(src, affine, shape, gain=None):

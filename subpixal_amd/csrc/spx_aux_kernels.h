@@ -2,7 +2,8 @@
 //   find_peak_kernel      centroid.find_peak in full generality (centroid.py:18-236)
 //   gather_cutouts_kernel frame -> fixed tiles (cutout.py:737-755, align.py:661)
 //   gen_pairs_kernel      synthetic Gaussian-spot pairs for bench / tests
-//   blot_affine4_kernel   the four half-pixel dithered blots of align.py:664-676 (poly5)
+//   blot_affine4_kernel   the four half-pixel dithered blots of align.py:664-676 (poly5), affine map
+//   blot_poly4_kernel     the same for a polynomial (distorted) coordinate map, degree <= 5
 // Needs spx_rt_hip.h (or the CPU harness) and spx_kernels.h first.
 #pragma once
 
@@ -134,6 +135,27 @@ SPX_DEVICE float blot_sample(const float* __restrict__ src, int ny, int nx, int 
     return aj * rowe + bj * rowm;
 }
 
+// value of the tile at source position (xs, ys): separable quintic through the six nearest
+// samples per axis; 0 outside the tile (tblot's `misval`)
+SPX_DEVICE float blot_resample(const float* __restrict__ tile, int sny, int snx, double xs, double ys) {
+    if (!(xs >= 0.0 && xs <= (double)(snx - 1) && ys >= 0.0 && ys <= (double)(sny - 1))) return 0.0f;
+    const int ix = (int)xs, iy = (int)ys;    // floor: both are >= 0
+    const float sx = (float)(xs - (double)ix), sy = (float)(ys - (double)iy);
+    float col[6];
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) {
+        float c[6];
+        const int j = iy - 2 + jj;
+        const bool inner = j >= 0 && j < sny && ix >= 2 && ix + 3 < snx;
+#pragma unroll
+        for (int ii = 0; ii < 6; ++ii)
+            c[ii] = inner ? tile[(int64_t)j * snx + ix - 2 + ii]
+                          : blot_sample(tile, sny, snx, j, ix - 2 + ii);
+        col[jj] = everett5(c, sx);
+    }
+    return everett5(col, sy);
+}
+
 SPX_TKERNEL(256)
 void blot_affine4_kernel(const float* __restrict__ src, int64_t nbatch, int sny, int snx,
                          const double* __restrict__ affine, const float* __restrict__ gain,
@@ -151,27 +173,58 @@ void blot_affine4_kernel(const float* __restrict__ src, int64_t nbatch, int sny,
         const double xt = (double)x + ox, yt = (double)y + oy;
         const double xs = a[0] * xt + a[1] * yt + a[2];
         const double ys = a[3] * xt + a[4] * yt + a[5];
-        float v = 0.0f;
-        if (xs >= 0.0 && xs <= (double)(snx - 1) && ys >= 0.0 && ys <= (double)(sny - 1)) {
-            const int ix = (int)xs, iy = (int)ys;    // floor: both are >= 0
-            const float sx = (float)(xs - (double)ix), sy = (float)(ys - (double)iy);
-            const float* tile = src + b * (int64_t)sny * snx;
-            float col[6];
-#pragma unroll
-            for (int jj = 0; jj < 6; ++jj) {
-                float c[6];
-                const int j = iy - 2 + jj;
-                const bool inner = j >= 0 && j < sny && ix >= 2 && ix + 3 < snx;
-#pragma unroll
-                for (int ii = 0; ii < 6; ++ii)
-                    c[ii] = inner ? tile[(int64_t)j * snx + ix - 2 + ii]
-                                  : blot_sample(tile, sny, snx, j, ix - 2 + ii);
-                col[jj] = everett5(c, sx);
-            }
-            v = everett5(col, sy);
-            if (gain) v *= gain[b];
-        }
+        float v = blot_resample(src + b * (int64_t)sny * snx, sny, snx, xs, ys);
+        if (gain) v *= gain[b];
         im4[g] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same four blots for a coordinate map that is NOT affine over the cutout (instrument
+// distortion: what BlotWCSMap evaluates per pixel at blot.py:71-76): per source a bivariate
+// polynomial of total degree `degree` <= 5 in the target position relative to the cutout centre,
+//   u = x + ox - (nx-1)/2,  v = y + oy - (ny-1)/2,
+//   xs = sum_{d=0..degree} sum_{i=d..0} cx[k] u^i v^(d-i),   k = d (d+1)/2 + (d - i)
+// (coef[b][0][k] for xs, coef[b][1][k] for ys; 21 slots per axis whatever the degree), evaluated
+// in float64 by Horner's rule in u per power of v.
+// ---------------------------------------------------------------------------
+constexpr int kBlotPolyTerms = 21;
+SPX_DEVICE double blot_poly_eval(const double* __restrict__ c, int degree, double u, double v) {
+    // sum over j (power of v) of v^j * (sum over i of c[i, j] u^i), i + j <= degree
+    double acc = 0.0, vj = 1.0;
+    for (int j = 0; j <= degree; ++j) {
+        double inner = 0.0;
+        for (int i = degree - j; i >= 0; --i) {
+            const int d = i + j;
+            inner = inner * u + c[d * (d + 1) / 2 + j];
+        }
+        acc += vj * inner;
+        vj *= v;
+    }
+    return acc;
+}
+
+SPX_TKERNEL(256)
+void blot_poly4_kernel(const float* __restrict__ src, int64_t nbatch, int sny, int snx,
+                       const double* __restrict__ coef, int degree, const float* __restrict__ gain,
+                       int ny, int nx, float* __restrict__ im4) {
+    const int64_t per = (int64_t)4 * ny * nx;
+    const int64_t total = nbatch * per;
+    const int64_t step = rt::grid_size() * 256;
+    const double xc = 0.5 * (double)(nx - 1), yc = 0.5 * (double)(ny - 1);
+    for (int64_t g = rt::block_id() * 256 + rt::thread_id(); g < total; g += step) {
+        const int64_t b = g / per;
+        const int r = (int)(g - b * per);
+        const int q = r / (ny * nx);                 // 0: 00, 1: 10, 2: 01, 3: 11
+        const int y = (r - q * ny * nx) / nx, x = r % nx;
+        const double u = (double)x + ((q & 1) ? 0.5 : 0.0) - xc;
+        const double v = (double)y + ((q & 2) ? 0.5 : 0.0) - yc;
+        const double* c = coef + (int64_t)b * 2 * kBlotPolyTerms;
+        const double xs = blot_poly_eval(c, degree, u, v);
+        const double ys = blot_poly_eval(c + kBlotPolyTerms, degree, u, v);
+        float val = blot_resample(src + b * (int64_t)sny * snx, sny, snx, xs, ys);
+        if (gain) val *= gain[b];
+        im4[g] = val;
     }
 }
 

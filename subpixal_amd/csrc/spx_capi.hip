@@ -565,6 +565,24 @@ int spx_blot_affine4_f32(const float* src, int64_t nbatch, int sny, int snx, con
     return 0;
 }
 
+int spx_blot_poly4_f32(const float* src, int64_t nbatch, int sny, int snx, const double* coef,
+                       int degree, const float* gain, int ny, int nx, float* im4, void* stream) {
+    if (nbatch < 0 || (nbatch > 0 && (!src || !coef || !im4)))
+        return fail(SPX_E_ARG, "null pointer or negative batch");
+    if (degree < 1 || degree > 5) return fail(SPX_E_ARG, "polynomial degree must be 1..5");
+    if (sny < 6 || snx < 6 || sny > 4096 || snx > 4096 || ny < 1 || nx < 1 || ny > 4096 || nx > 4096)
+        return fail(SPX_E_SHAPE, "source tiles must be 6..4096 px per side, targets 1..4096");
+    if (nbatch == 0) return 0;
+    const int64_t total = nbatch * 4 * ny * nx;
+    const int64_t blocks = (total + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
+    hipLaunchKernelGGL(spx::blot_poly4_kernel, dim3(grid), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), src, nbatch, sny, snx, coef, degree, gain,
+                       ny, nx, im4);
+    SPX_HIP(hipGetLastError());
+    return 0;
+}
+
 int spx_gen_gaussian_pairs_f32(uint64_t seed, int64_t first_index, int64_t nbatch, int n,
                                float sigma_lo, float sigma_hi, float max_shift, float* ref,
                                float* img, double* truth_dxdy, void* stream) {

@@ -219,4 +219,11 @@ extern "C" int emu_blot_affine4(const float* src, int64_t nbatch, int sny, int s
     rt::launch(3, 256, [&] { blot_affine4_kernel(src, nbatch, sny, snx, affine, gain, ny, nx, im4); }, 0);
     return 0;
 }
+
+extern "C" int emu_blot_poly4(const float* src, int64_t nbatch, int sny, int snx, const double* coef,
+                              int degree, const float* gain, int ny, int nx, float* im4) {
+    if (sny < 6 || snx < 6 || degree < 1 || degree > 5) return -2;
+    rt::launch(3, 256, [&] { blot_poly4_kernel(src, nbatch, sny, snx, coef, degree, gain, ny, nx, im4); }, 0);
+    return 0;
+}
 #endif   // EMU_PART 4

@@ -103,6 +103,20 @@ def blot_affine4(src, affine, ny, nx, gain=None):
     return im4
 
 
+def blot_poly4(src, coef, degree, ny, nx, gain=None):
+    src = np.ascontiguousarray(src, np.float32)
+    coef = np.ascontiguousarray(coef, np.float64)
+    n = src.shape[0]
+    im4 = np.zeros((n, 4, ny, nx), np.float32)
+    if gain is not None:
+        gain = np.ascontiguousarray(gain, np.float32)
+    rc = lib().emu_blot_poly4(_p(src, _fp), ctypes.c_int64(n), src.shape[1], src.shape[2],
+                              coef.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(degree),
+                              _p(gain, _fp), ny, nx, _p(im4, _fp))
+    assert rc == 0, rc
+    return im4
+
+
 def label_bboxes(seg, max_label):
     seg = np.ascontiguousarray(seg, np.int32)
     boxes = np.zeros((max_label + 1, 4), np.int32)

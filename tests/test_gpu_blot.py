@@ -96,3 +96,41 @@ def test_find_linear_fit_with_affine_blots():
     assert np.abs(np.abs(d.mean(axis=0)) - np.abs(shift)).max() < 0.03
     with pytest.raises(ValueError):
         find_linear_fit(imgs, drzs, affine=blot.shift_affine(n), blot=lambda a, b: a)
+
+
+def test_blot_poly4_distorted_map():
+    """8f-2 beyond affine: cubic-distorted maps through spx_blot_poly4_f32 vs the
+    oracle's float64 Lagrange restatement evaluated through the TRUE map; and the displacement the
+    reference-mode kernel finds on those blots equals the one found on the oracle's blots."""
+    from subpixal_amd import blot, cc
+    rng = np.random.default_rng(2)
+    n, sny, snx, ny, nx = 4, 60, 56, 32, 36
+    yy, xx = np.mgrid[0:sny, 0:snx].astype(float)
+    src = np.stack([np.exp(-((xx - 28 - k) ** 2 + (yy - 30 + k) ** 2) / (2 * 3.0 ** 2)) for k in range(n)])
+    src = (src + 0.01 * rng.normal(size=src.shape)).astype(np.float32)
+
+    def make(k):
+        def mapping(x, y):
+            u, v = x - 17.5, y - 15.5
+            xs = 10.0 + 0.3 * k + 0.99 * x + 0.03 * y + 2e-4 * u * u - 1e-4 * u * v + 3e-6 * u ** 3
+            ys = 13.5 - 0.02 * x + 1.01 * y + 1.5e-4 * v * v + 2e-6 * v ** 3 - 1e-6 * u * u * v
+            return xs, ys
+        return mapping
+    maps = [make(k) for k in range(n)]
+    coefs = np.empty((n, 2, blot.POLY_TERMS))
+    for k in range(n):
+        kind, (coefs[k], deg), res = blot.map_from(maps[k], (ny, nx))
+        assert kind == 'poly' and deg == 3 and res < 1e-6
+        assert blot.affine_from_map(maps[k], (ny, nx))[1] > 1e-3
+    got = blot.blot_poly4_batch(src, coefs, (ny, nx), 3)
+    exp = orc.blot_map4(src, maps, ny, nx)
+    assert got.shape == (n, 4, ny, nx) and got.dtype == np.float32
+    assert np.abs(got - exp).max() < 5e-6 * np.abs(exp).max()
+    # a reference cutout = the un-dithered blot displaced by a known amount; displacement via the
+    # GPU blots == displacement via the oracle's blots
+    ref = np.stack([np.roll(exp[k, 0], (1, -2), axis=(0, 1)) for k in range(n)]).astype(np.float32)
+    d_gpu = cc.find_displacement_batch(ref, got, cc_type='NCC')
+    d_orc, _ = orc.find_displacement_batch(ref, exp.astype(np.float32), 'NCC')
+    assert np.abs(d_gpu - d_orc).max() < 1e-4
+    with pytest.raises(ValueError):
+        blot.map_from(lambda x, y: (x + 5.0 + 1e-2 * np.sin(x), y + 5.0), (ny, nx), tol=1e-6)

@@ -297,3 +297,47 @@ def test_blot_affine4_logic_vs_oracle():
         xt = np.arange(8)[None, :] + ox + 4.25
         yt = np.arange(8)[:, None] + oy + 5.5
         assert np.abs(g[0, q] - poly(xt, yt)).max() < 2e-6 * np.abs(poly(xt, yt)).max()
+
+
+def test_blot_poly4_distorted_map_vs_oracle():
+    """8f-2 beyond affine: a cubic-distorted target -> source map, fitted by
+    blot.poly_from_map and resampled by the polynomial-map kernel, against the oracle's float64
+    Lagrange restatement evaluated through the TRUE map; the affine form of the same map is off
+    by more than 1e-3 px, which is why the polynomial form exists."""
+    from subpixal_amd import blot
+    rng = np.random.default_rng(2)
+    n, sny, snx, ny, nx = 3, 44, 40, 20, 24
+    src = rng.normal(size=(n, sny, snx)).astype(np.float32)
+
+    def make(k):
+        def mapping(x, y):          # rotation + scale + quadratic/cubic distortion (FLT-like)
+            u, v = x - 11.0, y - 9.0
+            xs = 8.0 + k + 0.99 * x + 0.03 * y + 2e-4 * u * u - 1e-4 * u * v + 3e-6 * u ** 3
+            ys = 9.5 - 0.02 * x + 1.01 * y + 1.5e-4 * v * v + 2e-6 * v ** 3 - 1e-6 * u * u * v
+            return xs, ys
+        return mapping
+    maps = [make(k) for k in range(n)]
+    coefs = np.empty((n, 2, blot.POLY_TERMS))
+    for k in range(n):
+        a, res1 = blot.affine_from_map(maps[k], (ny, nx))
+        assert res1 > 1e-3                                   # not affine at the 1e-3 px level
+        coefs[k], res3 = blot.poly_from_map(maps[k], (ny, nx), degree=3)
+        assert res3 < 1e-9
+        kind, (c, deg), res = blot.map_from(maps[k], (ny, nx))
+        assert kind == 'poly' and deg == 3 and res < 1e-3     # degree 2 is not enough
+    gain = rng.uniform(0.5, 2.0, n).astype(np.float32)
+    got = emu.blot_poly4(src, coefs, 3, ny, nx, gain)
+    exp = orc.blot_map4(src, maps, ny, nx, gain)
+    assert np.abs(got - exp).max() < 5e-6 * np.abs(exp).max()
+    assert ((exp == 0) == (got == 0)).all()
+    # degree 1 of the polynomial form == the affine kernel
+    a = np.array([[0.98, 0.05, 6.0, -0.04, 1.01, 7.2]] * n)
+    c1 = np.zeros((n, 2, blot.POLY_TERMS))
+    xc, yc = 0.5 * (nx - 1), 0.5 * (ny - 1)
+    c1[:, 0, 0] = a[:, 2] + a[:, 0] * xc + a[:, 1] * yc
+    c1[:, 0, 1], c1[:, 0, 2] = a[:, 0], a[:, 1]
+    c1[:, 1, 0] = a[:, 5] + a[:, 3] * xc + a[:, 4] * yc
+    c1[:, 1, 1], c1[:, 1, 2] = a[:, 3], a[:, 4]
+    assert np.array_equal(emu.blot_poly4(src, c1, 1, ny, nx), emu.blot_affine4(src, a, ny, nx))
+    with pytest.raises(ValueError):
+        blot.map_from(lambda x, y: (x + 5.0 + 1e-2 * np.sin(x), y + 5.0), (ny, nx), tol=1e-6)
