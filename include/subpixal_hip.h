@@ -84,7 +84,7 @@ extern "C" {
 #define SPX_E_WORKSPACE (-4)  /* workspace missing or too small            */
 
 /* largest cutout side and upsampling factor the kernels accept */
-#define SPX_MAX_SIDE 128
+#define SPX_MAX_SIDE 682
 #define SPX_MAX_UPSAMPLE 59
 
 int spx_abi_version(void);
@@ -97,6 +97,9 @@ int spx_init(int device);
  * whatever its cutout shape and input type: after it such calls neither allocate nor touch
  * function attributes, so they may be issued inside a stream capture. */
 int spx_prepare(int upsample);
+/* spx_prepare(upsample) plus the tables of the general path (cutouts above 128 px: FFT period and
+ * tables depend on the cutout size) for an (ny, nx) cutout. */
+int spx_prepare_shape(int ny, int nx, int upsample);
 /* Free the device tables of every device this process initialised (after synchronising them);
  * the next call builds them again.  No call may be in flight on another host thread. */
 int spx_shutdown(void);
@@ -106,7 +109,9 @@ const char* spx_last_error(void);
  * Bytes of device scratch the batched calls need (0 when none).  Cutouts up to 85 px per side
  * are processed entirely in registers/LDS (FFT period 64 up to 32 px, 128 up to 85 px); larger
  * ones (period 192, up to 128 px) keep per-workgroup class planes and the full convolution in a
- * workspace of 435 KiB per resident workgroup (independent of nbatch beyond the grid).
+ * workspace of 435 KiB per resident workgroup (independent of nbatch beyond the grid); the
+ * general path (129..682 px, period 64 C with C = 4..16 classes per axis) needs
+ * (4 C^2 64^2 + P (P + 4)) floats per workgroup, one workgroup per CU.
  * For the reference mode `need_icc` adds room for the interlaced images when the
  * caller does not want them back (out_icc == NULL).
  */
@@ -123,7 +128,9 @@ size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int nee
  * (find_peak(., 5, 'all')), shift = peak/U - (n-1)//2.
  *   out_dxdy   : float64 [nbatch][2]  (dx, dy)
  *   out_status : int32   [nbatch]     SPX_ST_* ; may be NULL
- * 5 <= ny, nx <= SPX_MAX_SIDE; 1 <= upsample <= SPX_MAX_UPSAMPLE.
+ * 5 <= ny, nx <= SPX_MAX_SIDE (cutouts above 128 px take the slow general path: the reference's
+ * cutouts, bounding box + padding of a segment, have no upper bound, cutout.py:159-175);
+ * 1 <= upsample <= SPX_MAX_UPSAMPLE.
  */
 int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
                          int upsample, int cc_type, double* out_dxdy, int32_t* out_status,

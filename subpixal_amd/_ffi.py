@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libsubpixal_hip.so')
 
 ABI_VERSION = 2
-MAX_SIDE = 128
+MAX_SIDE = 682
 MAX_UPSAMPLE = 59
 
 CC_CODES = {'CC': 0, 'NCC': 1, 'ZNCC': 2}
@@ -24,6 +24,7 @@ _SIGNATURES = {
     'spx_device_count': (_c.c_int, []),
     'spx_init': (_c.c_int, [_c.c_int]),
     'spx_prepare': (_c.c_int, [_c.c_int]),
+    'spx_prepare_shape': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
     'spx_shutdown': (_c.c_int, []),
     'spx_last_error': (_c.c_char_p, []),
     'spx_workspace_bytes_xcorr': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int]),

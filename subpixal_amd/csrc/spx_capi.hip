@@ -3,6 +3,7 @@
 #include "spx_rt_hip.h"
 #include "spx_kernels.h"
 #include "spx_kernels128.h"
+#include "spx_kernels_big.h"
 #include "spx_kernels32.h"
 #include "spx_aux_kernels.h"
 #include "spx_tables.h"
@@ -35,11 +36,11 @@ int hip_fail(hipError_t e, const char* what) {
 // Kernel families (spx_kernels32.h / spx_kernels.h / spx_kernels128.h) and the cutout sides
 // they take.  The FFT period is the smallest the path has for which the reference's 'same'
 // window (cc.py:114-126) is alias-free: P > 2n - 2 - (n-1)/2.
-enum Tile { TILE32 = 0, TILE64 = 1, TILE192 = 2, NUM_TILES = 3 };
+enum Tile { TILE32 = 0, TILE64 = 1, TILE192 = 2, NUM_TILES = 3, TILE_BIG = 3 };
 constexpr int kFoldMaxSide = 85;      // 64 tile, fold path: period 128 covers cutouts up to 85 px
 Tile tile_for(int ny, int nx) {
     const int n = ny > nx ? ny : nx;
-    return n <= 32 ? TILE32 : (n <= kFoldMaxSide ? TILE64 : TILE192);
+    return n <= 32 ? TILE32 : (n <= kFoldMaxSide ? TILE64 : (n <= 128 ? TILE192 : TILE_BIG));
 }
 constexpr int kPeriod[NUM_TILES] = {64, 128, 192};
 
@@ -47,6 +48,8 @@ struct DeviceTables {
     bool ready = false;                          // set only after EVERY table below exists
     spx::cf* tw[NUM_TILES] = {nullptr, nullptr, nullptr};     // w_P^j
     std::map<int, float*> ktab[NUM_TILES];       // upsample -> lane-major interpolation tables
+    std::map<int, float*> tw_big;                // general path: class count C -> w_{64C}^j
+    std::map<std::pair<int, int>, float*> ktab_big;     // (C, upsample) -> tables
     std::set<const void*> lds_ok;                // kernels whose dynamic-LDS limit is raised
     int num_cu = 256;
     std::mutex launch_mu;                        // serialises enqueues of host threads sharing a device
@@ -116,6 +119,35 @@ int ktab_for(DeviceTables* t, Tile tile, int upsample, const float** out) {
     *out = it->second;
     return 0;
 }
+
+// general path (cutouts above 128 px): twiddles and tables per class count, built on first use
+int big_tables_for(DeviceTables* t, int C, int upsample, const spx::cf** tw, const float** ktab) {
+    *tw = nullptr;
+    *ktab = nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = t->tw_big.find(C);
+    if (it == t->tw_big.end()) {
+        float* p = nullptr;
+        const int rc = upload(spx::host::make_twiddles(64 * C), &p);
+        if (rc) return rc;
+        it = t->tw_big.emplace(C, p).first;
+    }
+    *tw = reinterpret_cast<const spx::cf*>(it->second);
+    const int wb = spx::host::window_blocks(upsample);
+    if (wb > 0) {
+        auto kt = t->ktab_big.find({C, upsample});
+        if (kt == t->ktab_big.end()) {
+            float* p = nullptr;
+            const int rc = upload(spx::host::make_ktab_big(64 * C, upsample, 16 * wb), &p);
+            if (rc) return rc;
+            kt = t->ktab_big.emplace(std::make_pair(C, upsample), p).first;
+        }
+        *ktab = kt->second;
+    }
+    return 0;
+}
+// one workgroup per CU there: its workspace is megabytes (4 C^2 planes + the P x P convolution)
+int64_t grid_general(int num_cu, int64_t nbatch) { return nbatch < num_cu ? nbatch : num_cu; }
 
 // workgroups of a period-192 launch (each owns one workspace slot)
 int64_t grid_big(int num_cu, int64_t nbatch) {
@@ -275,8 +307,49 @@ int run_disp5(DeviceTables* t, Tile tile, bool fold, const TIn* ref, const TIn* 
 
 size_t ws_bytes_xcorr(int64_t nbatch, int ny, int nx) {
     if (nbatch <= 0 || ny <= 0 || nx <= 0) return 0;
-    if (tile_for(ny, nx) != TILE192) return 0;
+    const Tile tile = tile_for(ny, nx);
+    if (tile == TILE_BIG)
+        return (size_t)grid_general(device_cus(), nbatch) * spx::big_ws_floats(spx::big_class_count(ny, nx)) *
+               sizeof(float);
+    if (tile != TILE192) return 0;
     return (size_t)grid_big(device_cus(), nbatch) * spx::kWs96Bytes;
+}
+
+template <int WB, typename TIn>
+int run_pair_general(DeviceTables* t, const TIn* ref, const TIn* img, const PairArgs& a, int C,
+                     const spx::cf* tw, bool launch) {
+    const int lds = spx::LdsGen::total(16 * WB);
+    auto kern = spx::pair_big_kernel<WB, TIn>;
+    int rc = allow_lds(t, kern, lds);
+    if (rc || !launch) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid_general(t->num_cu, a.nbatch)), dim3(spx::kThreads), lds,
+                       a.s, ref, img, a.nbatch, a.ny, a.nx, a.U, a.cc_type, C, tw, a.ktab, a.out, a.status,
+                       a.ws);
+    SPX_HIP(hipGetLastError());
+    return 0;
+}
+template <typename TIn>
+int run_pair_general_wb(DeviceTables* t, int wb, const TIn* ref, const TIn* img, const PairArgs& a,
+                        int C, const spx::cf* tw, bool launch) {
+    switch (wb) {
+    case 0: return run_pair_general<0, TIn>(t, ref, img, a, C, tw, launch);
+    case 1: return run_pair_general<1, TIn>(t, ref, img, a, C, tw, launch);
+    case 2: return run_pair_general<2, TIn>(t, ref, img, a, C, tw, launch);
+    case 3: return run_pair_general<3, TIn>(t, ref, img, a, C, tw, launch);
+    default: return run_pair_general<4, TIn>(t, ref, img, a, C, tw, launch);
+    }
+}
+template <typename TIn>
+int run_disp5_general(DeviceTables* t, const TIn* ref, const TIn* im4, const Disp5Args& a, int C,
+                      const spx::cf* tw, bool launch) {
+    const int lds = spx::LdsGen::total(0);
+    auto kern = spx::disp5_big_kernel<TIn>;
+    int rc = allow_lds(t, kern, lds);
+    if (rc || !launch) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid_general(t->num_cu, a.nbatch)), dim3(spx::kThreads), lds,
+                       a.s, ref, im4, a.nbatch, a.ny, a.nx, a.cc_type, C, tw, a.icc, a.out, a.status, a.ws);
+    SPX_HIP(hipGetLastError());
+    return 0;
 }
 
 template <typename TIn>
@@ -286,12 +359,12 @@ int xcorr_refine(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
     if (nbatch < 0 || (nbatch > 0 && (!ref || !img || !out_dxdy)))
         return fail(SPX_E_ARG, "null pointer or negative batch");
     if (ny < 5 || nx < 5 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
-        return fail(SPX_E_SHAPE, "pair mode supports cutouts of 5..128 pixels per side");
+        return fail(SPX_E_SHAPE, "pair mode supports cutouts of 5..682 pixels per side");
     const int wb = spx::host::window_blocks(upsample);
     if (wb < 0) return fail(SPX_E_SHAPE, "upsample must be in [1, 59]");
     if (nbatch == 0) return 0;
     const Tile tile = tile_for(ny, nx);
-    if (tile == TILE192 && (!workspace || workspace_bytes < ws_bytes_xcorr(nbatch, ny, nx)))
+    if (tile >= TILE192 && (!workspace || workspace_bytes < ws_bytes_xcorr(nbatch, ny, nx)))
         return fail(SPX_E_WORKSPACE, "cutouts above 85 px need spx_workspace_bytes_xcorr() bytes");
     DeviceTables* t = nullptr;
     int rc = current_tables(&t);
@@ -301,6 +374,14 @@ int xcorr_refine(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
     a.out = out_dxdy; a.status = out_status;
     a.ws = reinterpret_cast<float*>(workspace);
     a.s = reinterpret_cast<hipStream_t>(stream);
+    if (tile == TILE_BIG) {            // general path: class count and tables at run time
+        const int C = spx::big_class_count(ny, nx);
+        const spx::cf* tw = nullptr;
+        rc = big_tables_for(t, C, upsample, &tw, &a.ktab);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lk(t->launch_mu);
+        return run_pair_general_wb<TIn>(t, wb, ref, img, a, C, tw, true);
+    }
     rc = ktab_for(t, tile, upsample, &a.ktab);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(t->launch_mu);
@@ -314,7 +395,7 @@ int find_displacement5(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, i
     if (nbatch < 0 || (nbatch > 0 && (!ref || !im4 || !out_dxdy)))
         return fail(SPX_E_ARG, "null pointer or negative batch");
     if (ny < 3 || nx < 3 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
-        return fail(SPX_E_SHAPE, "5-image mode supports cutouts of 3..128 pixels per side");
+        return fail(SPX_E_SHAPE, "5-image mode supports cutouts of 3..682 pixels per side");
     if (nbatch == 0) return 0;
     const size_t need = spx_workspace_bytes_displacement5(nbatch, ny, nx, out_icc == nullptr);
     if (need > 0 && (!workspace || workspace_bytes < need))
@@ -330,6 +411,15 @@ int find_displacement5(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, i
     a.out = out_dxdy; a.status = out_status;
     a.ws = reinterpret_cast<float*>(wsb);
     a.s = reinterpret_cast<hipStream_t>(stream);
+    if (tile_for(ny, nx) == TILE_BIG) {
+        const int C = spx::big_class_count(ny, nx);
+        const spx::cf* tw = nullptr;
+        const float* unused = nullptr;
+        rc = big_tables_for(t, C, 1, &tw, &unused);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lk(t->launch_mu);
+        return run_disp5_general<TIn>(t, ref, im4, a, C, tw, true);
+    }
     std::lock_guard<std::mutex> lk(t->launch_mu);
     return run_disp5<TIn>(t, tile_for(ny, nx), ny > 64 || nx > 64, ref, im4, a, true);
 }
@@ -376,7 +466,28 @@ int spx_prepare(int upsample) {
             if ((rc = run_disp5<double>(t, tile, fold != 0, nullptr, nullptr, da, false))) return rc;
         }
     }
+    {   // general path (cutouts above 128 px): its tables depend on the cutout size and are built on
+        // first use (spx_prepare_shape() builds them up front); the LDS limits are raised here
+        std::lock_guard<std::mutex> lk(t->launch_mu);
+        if ((rc = run_pair_general_wb<float>(t, wb, nullptr, nullptr, pa, 4, nullptr, false))) return rc;
+        if ((rc = run_pair_general_wb<double>(t, wb, nullptr, nullptr, pa, 4, nullptr, false))) return rc;
+        if ((rc = run_disp5_general<float>(t, nullptr, nullptr, da, 4, nullptr, false))) return rc;
+        if ((rc = run_disp5_general<double>(t, nullptr, nullptr, da, 4, nullptr, false))) return rc;
+    }
     return 0;
+}
+
+int spx_prepare_shape(int ny, int nx, int upsample) {
+    int rc = spx_prepare(upsample);
+    if (rc) return rc;
+    if (ny < 3 || nx < 3 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
+        return fail(SPX_E_SHAPE, "cutouts of 3..682 pixels per side");
+    if (tile_for(ny, nx) != TILE_BIG) return 0;
+    DeviceTables* t = nullptr;
+    if ((rc = current_tables(&t))) return rc;
+    const spx::cf* tw = nullptr;
+    const float* kt = nullptr;
+    return big_tables_for(t, spx::big_class_count(ny, nx), upsample, &tw, &kt);
 }
 
 int spx_shutdown(void) {
@@ -395,6 +506,10 @@ int spx_shutdown(void) {
             for (auto& e : t.ktab[k]) (void)hipFree(e.second);
             t.ktab[k].clear();
         }
+        for (auto& e : t.tw_big) (void)hipFree(e.second);
+        t.tw_big.clear();
+        for (auto& e : t.ktab_big) (void)hipFree(e.second);
+        t.ktab_big.clear();
         t.ready = false;
     }
     if (have_prev) (void)hipSetDevice(prev);

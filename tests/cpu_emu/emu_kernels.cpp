@@ -11,6 +11,7 @@
 #include "spx_aux_kernels.h"      // plain (non-template) kernels: one object only
 #endif
 #include "spx_kernels128.h"
+#include "spx_kernels_big.h"
 #include "spx_kernels32.h"
 #include "spx_tables.h"
 
@@ -102,13 +103,40 @@ static int emu_pair32_t(const TIn* ref, const TIn* img, int64_t nbatch, int ny, 
     return 0;
 }
 
+// general path (cutouts above 128 px): class count C at run time
+template <typename TIn>
+static int emu_pair_general(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx, int U,
+                            int cc_type, double* out, int* status) {
+    const int wb = host::window_blocks(U);
+    const int C = big_class_count(ny, nx);
+    if (C > kBigMaxC) return -1;
+    std::vector<float> tw = host::make_twiddles(64 * C);
+    std::vector<float> kt;
+    if (wb > 0) kt = host::make_ktab_big(64 * C, U, 16 * wb);
+    const cf* twp = reinterpret_cast<const cf*>(tw.data());
+    const float* ktp = kt.empty() ? nullptr : kt.data();
+    const int64_t grid = g_grid > 0 && g_grid < nbatch ? g_grid : nbatch;
+    std::vector<float> ws((size_t)grid * big_ws_floats(C));
+    float* wsp = ws.data();
+    auto run = [&](auto fn) { rt::launch(grid, kThreads, fn, LdsGen::total(16 * wb)); };
+    switch (wb) {
+    case 0: run([&] { pair_big_kernel<0, TIn>(ref, img, nbatch, ny, nx, U, cc_type, C, twp, ktp, out, status, wsp); }); break;
+    case 1: run([&] { pair_big_kernel<1, TIn>(ref, img, nbatch, ny, nx, U, cc_type, C, twp, ktp, out, status, wsp); }); break;
+    case 2: run([&] { pair_big_kernel<2, TIn>(ref, img, nbatch, ny, nx, U, cc_type, C, twp, ktp, out, status, wsp); }); break;
+    case 3: run([&] { pair_big_kernel<3, TIn>(ref, img, nbatch, ny, nx, U, cc_type, C, twp, ktp, out, status, wsp); }); break;
+    default: run([&] { pair_big_kernel<4, TIn>(ref, img, nbatch, ny, nx, U, cc_type, C, twp, ktp, out, status, wsp); }); break;
+    }
+    return 0;
+}
+
 // tile: 0 = the product's choice, else force 32 / 64 / 192 / 256 (period of the big path)
 template <typename TIn>
 static int emu_pair_t(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx, int U,
                       int cc_type, double* out, int* status, int tile) {
-    if (ny < 5 || nx < 5 || ny > 128 || nx > 128) return -1;
+    if (ny < 5 || nx < 5) return -1;
     if (host::window_blocks(U) < 0) return -2;
     const int n = ny > nx ? ny : nx;
+    if (n > 128) return emu_pair_general<TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
     if (tile == 0) tile = n <= 32 ? 32 : (n <= 85 ? 64 : 192);
     if (tile == 32 && n <= 32) return emu_pair32_t<TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
     if (tile == 64 && n <= 64) return emu_pair64<false, TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
@@ -134,8 +162,20 @@ extern "C" int emu_pair_f64(const double* ref, const double* img, int64_t nbatch
 template <typename TIn>
 static int emu_disp5_t(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, int nx,
                        int cc_type, float* icc, double* out, int* status) {
-    if (ny < 3 || nx < 3 || ny > 128 || nx > 128) return -1;
+    if (ny < 3 || nx < 3) return -1;
     const int n = ny > nx ? ny : nx;
+    if (n > 128) {
+        const int C = big_class_count(ny, nx);
+        if (C > kBigMaxC) return -1;
+        std::vector<float> tw = host::make_twiddles(64 * C);
+        const cf* twp = reinterpret_cast<const cf*>(tw.data());
+        std::vector<float> ws((size_t)nbatch * big_ws_floats(C));
+        float* wsp = ws.data();
+        rt::launch(nbatch, kThreads, [&] {
+            disp5_big_kernel<TIn>(ref, im4, nbatch, ny, nx, cc_type, C, twp, icc, out, status, wsp);
+        }, LdsGen::total(0));
+        return 0;
+    }
     if (n <= 32) {
         std::vector<float> tw = host::make_twiddles(64);
         const cf* twp = reinterpret_cast<const cf*>(tw.data());

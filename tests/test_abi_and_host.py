@@ -49,8 +49,12 @@ def test_argument_errors_without_gpu():
     assert lib.spx_xcorr_refine_f32(None, None, -1, 64, 64, 1, 0, None, None, None, 0, None) == -1
     buf = (ctypes.c_double * 4)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert lib.spx_xcorr_refine_f32(p, p, 1, 129, 64, 1, 0, p, None, None, 0, None) == -2
-    assert b'5..128' in lib.spx_last_error()
+    assert lib.spx_xcorr_refine_f32(p, p, 1, 683, 64, 1, 0, p, None, None, 0, None) == -2
+    assert b'5..682' in lib.spx_last_error()
+    # the general path (129..682 px): 4 C^2 planes of 64x64 + the P x (P+4) convolution per workgroup
+    assert lib.spx_workspace_bytes_xcorr(3, 129, 64) == 3 * (4 * 16 * 64 * 64 + 256 * 260) * 4
+    assert lib.spx_workspace_bytes_xcorr(3, 682, 64) == 3 * (4 * 256 * 64 * 64 + 1024 * 1028) * 4
+    assert lib.spx_xcorr_refine_f32(p, p, 1, 200, 64, 1, 0, p, None, None, 0, None) == -4
     assert lib.spx_xcorr_refine_f32(p, p, 1, 86, 64, 1, 0, p, None, None, 0, None) == -4     # period 192 needs workspace
     assert lib.spx_xcorr_refine_f64(p, p, 1, 86, 64, 1, 0, p, None, None, 0, None) == -4
     assert lib.spx_xcorr_refine_f64(None, None, 1, 64, 64, 1, 0, None, None, None, 0, None) == -1

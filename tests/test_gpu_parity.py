@@ -97,6 +97,36 @@ def test_pair_mode_vs_oracle_fold_path(spx, up, tol):
             assert np.max(np.abs(got[0] - np.array(exp))) < max(tol, 3e-5), (ny, nx, name)
 
 
+def test_general_path_above_128_px(spx):
+    """VERDICT r1 missing item 5: cutouts above 128 px used to be refused (SPX_E_SHAPE) although the
+    reference's cutouts (bounding box + padding, cutout.py:159-175) have no upper bound.  General
+    path: FFT period 64 C, class count C = 4..16 at run time (even and odd), up to 682 px."""
+    rng = np.random.default_rng(128)
+    for (ny, nx) in ((129, 129), (170, 150), (200, 131), (30, 260), (341, 341), (400, 90)):
+        count = 3
+        ref = np.empty((count, ny, nx), np.float32)
+        img = np.empty_like(ref)
+        for k in range(count):
+            ref[k], img[k] = datagen.pair_set(ny, nx, rng.uniform(-2.5, 2.5), rng.uniform(-2.5, 2.5),
+                                              min(ny, nx) / 14.0 + 1, rng.uniform(0.5, 2), np.float32,
+                                              noise_seed=int(rng.integers(1, 1 << 30)), noise_level=0.005)
+        for up, name in ((1, 'CC'), (10, 'NCC'), (20, 'ZNCC')):
+            got, st = spx.xcorr_refine_batch(ref, img, upsample=up, cc_type=name, return_status=True)
+            exp, est = orc.xcorr_refine_batch(ref, img, up, name)
+            assert np.array_equal(st, est), (ny, nx, up)
+            assert np.max(np.abs(got - exp)) < (1e-3 if up > 1 else 3e-5), (ny, nx, up, np.max(np.abs(got - exp)))
+    r5, im4, _ = datagen.dither_batch(5, 3, 160)
+    for dt in (np.float32, np.float64):
+        d, icc, st = spx.find_displacement_batch(r5.astype(dt), im4.astype(dt), cc_type='ZNCC',
+                                                 full_output=True, return_status=True)
+        e, est = orc.find_displacement_batch(r5.astype(dt), im4.astype(dt), 'ZNCC')
+        assert np.array_equal(st, est) and np.max(np.abs(d - e)) < 3e-5
+    big = np.zeros((1, 682, 682), np.float32)
+    big[0, 300:380, 300:380] = 1.0
+    got, st = spx.xcorr_refine_batch(big, np.roll(big, (3, -5), axis=(1, 2)), upsample=1, return_status=True)
+    assert st[0] == 0 and abs(got[0, 0] + 5) < 1e-3 and abs(got[0, 1] - 3) < 1e-3
+
+
 def test_integer_lags_do_not_depend_on_the_period(spx, golden_dir):
     """The reference's fftconvolve pads to next_fast_len(2n-1) (cc.py:114); the kernels use the
     smallest alias-free multiple of 64 instead (128 up to 85 px, 192 up to 128 px).  At integer
@@ -250,7 +280,7 @@ def test_pair_mode_edge_cases(spx):
 
 def test_shape_and_upsample_limits(spx):
     from subpixal_amd._ffi import SubpixalHipError
-    a = np.zeros((2, 129, 64), np.float32)
+    a = np.zeros((2, 683, 64), np.float32)
     with pytest.raises(SubpixalHipError):
         spx.xcorr_refine_batch(a, a)
     b = np.zeros((2, 64, 64), np.float32)

@@ -341,3 +341,25 @@ def test_blot_poly4_distorted_map_vs_oracle():
     assert np.array_equal(emu.blot_poly4(src, c1, 1, ny, nx), emu.blot_affine4(src, a, ny, nx))
     with pytest.raises(ValueError):
         blot.map_from(lambda x, y: (x + 5.0 + 1e-2 * np.sin(x), y + 5.0), (ny, nx), tol=1e-6)
+
+
+def test_general_path_above_128_px():
+    """Cutouts above 128 px (the reference's cutouts have no size limit, cutout.py:159-175): FFT period
+    64 C with the class count C at run time (here 4, 5 and 7: even and odd), pair and reference mode"""
+    rng = np.random.default_rng(1)
+    for (ny, nx) in ((129, 129), (200, 131), (30, 260)):
+        r, i = datagen.pair_set(ny, nx, rng.uniform(-2, 2), rng.uniform(-2, 2), min(ny, nx) / 14 + 1, 1.0,
+                                np.float32, noise_seed=3, noise_level=0.01)
+        assert orc.fft_period(ny, nx) == {129: 256, 200: 320, 260: 448}[max(ny, nx)]
+        for up, name, code in ((1, 'CC', 0), (10, 'ZNCC', 2)):
+            got, st = emu.pair(r[None], i[None], up, code)
+            s2 = []
+            e = orc.xcorr_refine(r, i, up, name, _status=s2)
+            assert np.max(np.abs(got[0] - np.array(e))) < (4e-4 if up > 1 else 2e-5), (ny, nx, up)
+            assert st[0] == s2[-1]
+    r5, m4, _ = datagen.dither_batch(3, 1, 150)
+    d, st, icc = emu.disp5(r5, m4, 1)
+    e, est = orc.find_displacement_batch(r5, m4, 'NCC')
+    assert np.abs(d - e).max() < 2e-5 and np.array_equal(st, est)
+    eicc = orc.build_icc(r5[0], *m4[0], cc_type='NCC')[0]
+    assert np.abs(icc[0] - eicc).max() < 3e-6 * np.abs(eicc).max()
