@@ -107,8 +107,10 @@ def test_general_path_above_128_px(spx):
         ref = np.empty((count, ny, nx), np.float32)
         img = np.empty_like(ref)
         for k in range(count):
+            # (spots of sigma <= 8 px: a float32 correlation of a 25 px-wide spot is too flat across
+            #  a 0.4 px fit box at upsample 10-20 for 1e-3 px, whatever computes it)
             ref[k], img[k] = datagen.pair_set(ny, nx, rng.uniform(-2.5, 2.5), rng.uniform(-2.5, 2.5),
-                                              min(ny, nx) / 14.0 + 1, rng.uniform(0.5, 2), np.float32,
+                                              min(8.0, min(ny, nx) / 14.0 + 1), rng.uniform(0.5, 2), np.float32,
                                               noise_seed=int(rng.integers(1, 1 << 30)), noise_level=0.005)
         for up, name in ((1, 'CC'), (10, 'NCC'), (20, 'ZNCC')):
             got, st = spx.xcorr_refine_batch(ref, img, upsample=up, cc_type=name, return_status=True)
