@@ -58,10 +58,11 @@ struct DeviceTables {
 std::mutex g_mu;                                 // guards g_dev and every DeviceTables' maps
 std::map<int, DeviceTables> g_dev;
 
-int upload(const std::vector<float>& h, float** out) {
+// (float64 tables travel as opaque `float*` device pointers too and are cast back at the launch)
+template <typename T> int upload(const std::vector<T>& h, float** out) {
     void* p = nullptr;
-    SPX_HIP(hipMalloc(&p, h.size() * sizeof(float)));
-    const hipError_t e = hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+    SPX_HIP(hipMalloc(&p, h.size() * sizeof(T)));
+    const hipError_t e = hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(p);
         return hip_fail(e, "hipMemcpy(table)");
@@ -108,11 +109,11 @@ int ktab_for(DeviceTables* t, Tile tile, int upsample, const float** out) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = t->ktab[tile].find(upsample);
     if (it == t->ktab[tile].end()) {
-        std::vector<float> k = tile == TILE32 ? spx::host::make_ktab32(upsample, 16 * wb)
-                             : tile == TILE64 ? spx::host::make_ktab(128, upsample, 16 * wb)
-                                              : spx::host::make_ktab_big(192, upsample, 16 * wb);
         float* p = nullptr;
-        const int rc = upload(k, &p);
+        // period 192: float64 tables (its refine stage accumulates in float64)
+        const int rc = tile == TILE32 ? upload(spx::host::make_ktab32(upsample, 16 * wb), &p)
+                     : tile == TILE64 ? upload(spx::host::make_ktab(128, upsample, 16 * wb), &p)
+                                      : upload(spx::host::make_ktab_big_f64(192, upsample, 16 * wb), &p);
         if (rc) return rc;
         it = t->ktab[tile].emplace(upsample, p).first;
     }
@@ -138,7 +139,7 @@ int big_tables_for(DeviceTables* t, int C, int upsample, const spx::cf** tw, con
         auto kt = t->ktab_big.find({C, upsample});
         if (kt == t->ktab_big.end()) {
             float* p = nullptr;
-            const int rc = upload(spx::host::make_ktab_big(64 * C, upsample, 16 * wb), &p);
+            const int rc = upload(spx::host::make_ktab_big_f64(64 * C, upsample, 16 * wb), &p);
             if (rc) return rc;
             kt = t->ktab_big.emplace(std::make_pair(C, upsample), p).first;
         }
@@ -234,8 +235,8 @@ int run_pair192(DeviceTables* t, const TIn* ref, const TIn* img, const PairArgs&
     int rc = allow_lds(t, kern, lds);
     if (rc || !launch) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid_big(t->num_cu, a.nbatch)), dim3(spx::kThreads), lds, a.s,
-                       ref, img, a.nbatch, a.ny, a.nx, a.U, a.cc_type, t->tw[TILE192], a.ktab, a.out,
-                       a.status, a.ws);
+                       ref, img, a.nbatch, a.ny, a.nx, a.U, a.cc_type, t->tw[TILE192],
+                       reinterpret_cast<const double*>(a.ktab), a.out, a.status, a.ws);
     SPX_HIP(hipGetLastError());
     return 0;
 }
@@ -323,8 +324,8 @@ int run_pair_general(DeviceTables* t, const TIn* ref, const TIn* img, const Pair
     int rc = allow_lds(t, kern, lds);
     if (rc || !launch) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid_general(t->num_cu, a.nbatch)), dim3(spx::kThreads), lds,
-                       a.s, ref, img, a.nbatch, a.ny, a.nx, a.U, a.cc_type, C, tw, a.ktab, a.out, a.status,
-                       a.ws);
+                       a.s, ref, img, a.nbatch, a.ny, a.nx, a.U, a.cc_type, C, tw,
+                       reinterpret_cast<const double*>(a.ktab), a.out, a.status, a.ws);
     SPX_HIP(hipGetLastError());
     return 0;
 }

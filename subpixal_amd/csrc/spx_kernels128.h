@@ -379,16 +379,23 @@ SPX_DEVICE float window_value128(const float* __restrict__ conv, int ny, int nx,
 // leaves its partial window in its own LDS buffer; the reader adds the four (fine_value128).
 // Inside the wave, A-row lj of column tile t is column CW w + TPW lj + t, so that a lane's tiles
 // are TPW consecutive columns = ONE 12- or 16-byte load per row; accumulator register r of tile t
-// is then column CW w + 4 TPW lk + TPW r + t.  Tables (spx_tables.h make_ktab_big), lane = 16 lk + lj:
+// is then column CW w + TPW (lk + 4 r) + t.  Tables (spx_tables.h make_ktab_big), lane = 16 lk + lj:
 //   [0][blk][lane][s]       = K(-(16 blk + lj - W/2)/U - (4 s + lk - P/2)),       s in [0, P/4)
-//   [1][blk][lane][4 T + r] = K(-(16 blk + lj - W/2)/U - (CW w + 4 TPW lk + TPW r + t - P/2)), T = TPW w + t
+//   [1][blk][lane][4 T + r] = K(-(16 blk + lj - W/2)/U - (CW w + TPW (lk + 4 r) + t - P/2)), T = TPW w + t
+// (make_ktab_big_f64).
+// The contractions accumulate in float64 (v_mfma_f64_16x16x4_f64, float64 tables): a float32
+// chain over the P rows loses ~1e-7 of the peak value, which on a fine grid 20-60x flatter than
+// the pixel grid is worth up to 2e-3 px at upsample >= 27; in float64 the float32 transforms
+// themselves are the limit (~1e-5 px).  Its C/D map has row = lk + 4 r.
 template <int TPW> struct __attribute__((packed, aligned(4))) RowFrag { float v[TPW]; };
+struct __attribute__((aligned(16))) F64x2 { double v[2]; };
 template <int C, int WB>
-SPX_DEVICE void fine_window128(unsigned char* lds, const float* __restrict__ ktab,
+SPX_DEVICE void fine_window128(unsigned char* lds, const double* __restrict__ ktab,
                                const float* __restrict__ conv, int ny, int nx, int qyc, int qxc) {
     typedef LdsBig<C> L;
+    typedef rt::f64x4 f64x4;
     constexpr int W = 16 * WB;
-    constexpr int NQ = L::P / 16;            // 16-byte table entries per (block, lane)
+    constexpr int NQ = L::P / 16;            // groups of 4 table entries per (block, lane)
     constexpr int CW = L::P / 4;             // window columns per wave
     constexpr int TPW = CW / 16;             // column tiles per wave
     const int tid = fresh_tid();
@@ -400,20 +407,23 @@ SPX_DEVICE void fine_window128(unsigned char* lds, const float* __restrict__ kta
     qxc = qxc < 0 ? 0 : (qxc > nx - 1 ? nx - 1 : qxc);
     const int lyc = conv_index(ny, qyc), lxc = conv_index(nx, qxc);
     ktab = rt::launder(ktab);
-    const f32x4* kty = reinterpret_cast<const f32x4*>(ktab) + (size_t)lane * NQ;
-    const f32x4* ktx = reinterpret_cast<const f32x4*>(ktab) + (size_t)(WB * 64 + lane) * NQ;
+    const F64x2* kty = reinterpret_cast<const F64x2*>(ktab) + (size_t)lane * NQ * 2;
+    const F64x2* ktx = reinterpret_cast<const F64x2*>(ktab) + (size_t)(WB * 64 + lane) * NQ * 2;
 
-    f32x4 acc[WB][TPW];
+    f64x4 acc[WB][TPW];
 #pragma unroll
     for (int ab = 0; ab < WB; ++ab)
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[ab][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TPW; ++t) acc[ab][t] = f64x4{0., 0., 0., 0.};
     const int col0 = L::wrap(lxc + CW * wave + TPW * lj - L::P / 2);     // + t (wrap copy in the row)
-#pragma unroll 4
+#pragma unroll 2
     for (int s4 = 0; s4 < NQ; ++s4) {
-        f32x4 kb[WB];
+        double kb[WB][4];
 #pragma unroll
-        for (int ab = 0; ab < WB; ++ab) kb[ab] = kty[(size_t)ab * 64 * NQ + s4];
+        for (int ab = 0; ab < WB; ++ab) {
+            const F64x2 lo = kty[((size_t)ab * 64 * NQ + s4) * 2], hi = kty[((size_t)ab * 64 * NQ + s4) * 2 + 1];
+            kb[ab][0] = lo.v[0]; kb[ab][1] = lo.v[1]; kb[ab][2] = hi.v[0]; kb[ab][3] = hi.v[1];
+        }
         RowFrag<TPW> a4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -426,33 +436,32 @@ SPX_DEVICE void fine_window128(unsigned char* lds, const float* __restrict__ kta
             for (int t = 0; t < TPW; ++t)
 #pragma unroll
                 for (int ab = 0; ab < WB; ++ab)
-                    acc[ab][t] = rt::mfma_16x16x4(a4[e].v[t], kb[ab][e], acc[ab][t]);
+                    acc[ab][t] = rt::mfma_f64_16x16x4((double)a4[e].v[t], kb[ab][e], acc[ab][t]);
     }
-    f32x4 f[WB][WB];
+    // stage 2, one block of fine x offsets at a time (keeps the accumulators of large windows
+    // within the register file)
 #pragma unroll
-    for (int bb = 0; bb < WB; ++bb)
+    for (int bb = 0; bb < WB; ++bb) {
+        f64x4 f[WB];
 #pragma unroll
-        for (int ab = 0; ab < WB; ++ab) f[bb][ab] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ab = 0; ab < WB; ++ab) f[ab] = f64x4{0., 0., 0., 0.};
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        f32x4 ka[WB];
+        for (int t = 0; t < TPW; ++t) {
+            const size_t q = ((size_t)bb * 64 * NQ + TPW * wave + t) * 2;
+            const F64x2 lo = ktx[q], hi = ktx[q + 1];
+            const double ka[4] = {lo.v[0], lo.v[1], hi.v[0], hi.v[1]};
 #pragma unroll
-        for (int bb = 0; bb < WB; ++bb) ka[bb] = ktx[(size_t)bb * 64 * NQ + TPW * wave + t];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int bb = 0; bb < WB; ++bb)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int ab = 0; ab < WB; ++ab)
-                    f[bb][ab] = rt::mfma_16x16x4(ka[bb][r], acc[ab][t][r], f[bb][ab]);
-    }
-#pragma unroll
-    for (int bb = 0; bb < WB; ++bb)
+                    f[ab] = rt::mfma_f64_16x16x4(ka[r], acc[ab][t][r], f[ab]);
+        }
 #pragma unroll
         for (int ab = 0; ab < WB; ++ab)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                fbuf[(bb * 16 + 4 * lk + r) * W + ab * 16 + lj] = f[bb][ab][r];
+                fbuf[(bb * 16 + lk + 4 * r) * W + ab * 16 + lj] = (float)f[ab][r];
+    }
     rt::block_sync_lds();
 }
 
@@ -469,7 +478,7 @@ template <int W> SPX_DEVICE float fine_value128(const unsigned char* lds, int b,
 // ---------------------------------------------------------------------------
 template <int C, int WB, int DBG, typename TIn>
 SPX_DEVICE void pair128_body(const TIn* __restrict__ ref, const TIn* __restrict__ img, int ny,
-                             int nx, int U, int cc_type, const float* __restrict__ ktab,
+                             int nx, int U, int cc_type, const double* __restrict__ ktab,
                              double* __restrict__ out, int* __restrict__ status,
                              unsigned char* lds, float* __restrict__ ws, PhaseClock<DBG>& clk) {
     typedef LdsBig<C> L;
@@ -563,7 +572,7 @@ template <int C> SPX_DEVICE void load_twiddles128(unsigned char* lds, const cf* 
 template <int C, int WB, int DBG = 0, typename TIn = float>
 SPX_TKERNEL(256) void pair128_kernel(const TIn* __restrict__ ref, const TIn* __restrict__ img,
                                      int64_t nbatch, int ny, int nx, int U, int cc_type,
-                                     const cf* __restrict__ tw_g, const float* __restrict__ ktab,
+                                     const cf* __restrict__ tw_g, const double* __restrict__ ktab,
                                      double* __restrict__ out, int* __restrict__ status,
                                      float* __restrict__ workspace) {
     SPX_DYN_LDS(lds);

@@ -295,11 +295,13 @@ SPX_DEVICE void window_scan_big(const float* __restrict__ conv, const BigGeom& G
     }
 }
 
-// Fine window by MFMA, period P at run time: wave w takes the window columns
-// [CW w - P/2, CW w - P/2 + CW), CW = P/4, one 16-column tile at a time (tables: make_ktab_big).
+// Fine window by MFMA (float64 accumulation, see fine_window128), period P at run time: wave w
+// takes the window columns [CW w - P/2, CW w - P/2 + CW), CW = P/4, one 16-column tile at a time
+// (tables: make_ktab_big_f64).
 template <int WB>
-SPX_DEVICE void fine_window_big(unsigned char* lds, const BigGeom& G, const float* __restrict__ ktab,
+SPX_DEVICE void fine_window_big(unsigned char* lds, const BigGeom& G, const double* __restrict__ ktab,
                                 const float* __restrict__ conv, int ny, int nx, int qyc, int qxc) {
+    typedef rt::f64x4 f64x4;
     constexpr int W = 16 * WB;
     const int P = G.P, NQ = P / 16, CW = P / 4, TPW = CW / 16;
     const int tid = fresh_tid();
@@ -309,40 +311,37 @@ SPX_DEVICE void fine_window_big(unsigned char* lds, const BigGeom& G, const floa
     qyc = qyc < 0 ? 0 : (qyc > ny - 1 ? ny - 1 : qyc);
     qxc = qxc < 0 ? 0 : (qxc > nx - 1 ? nx - 1 : qxc);
     const int lyc = conv_index(ny, qyc), lxc = conv_index(nx, qxc);
-    const f32x4* kty = reinterpret_cast<const f32x4*>(ktab) + (size_t)lane * NQ;
-    const f32x4* ktx = reinterpret_cast<const f32x4*>(ktab) + ((size_t)WB * 64 + lane) * NQ;
-    f32x4 f[WB][WB];
+    const double* kty = ktab + (size_t)lane * NQ * 4;
+    const double* ktx = ktab + ((size_t)WB * 64 + lane) * NQ * 4;
+    f64x4 f[WB][WB];
 #pragma unroll
     for (int bb = 0; bb < WB; ++bb)
 #pragma unroll
-        for (int ab = 0; ab < WB; ++ab) f[bb][ab] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ab = 0; ab < WB; ++ab) f[bb][ab] = f64x4{0., 0., 0., 0.};
     for (int t = 0; t < TPW; ++t) {
         const int col = G.wrap(lxc + CW * wave + TPW * lj + t - P / 2);
-        f32x4 acc[WB];
+        f64x4 acc[WB];
 #pragma unroll
-        for (int ab = 0; ab < WB; ++ab) acc[ab] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ab = 0; ab < WB; ++ab) acc[ab] = f64x4{0., 0., 0., 0.};
         for (int s4 = 0; s4 < NQ; ++s4) {
-            f32x4 kb[WB];
-#pragma unroll
-            for (int ab = 0; ab < WB; ++ab) kb[ab] = kty[(size_t)ab * 64 * NQ + s4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = G.wrap(lyc + 4 * (4 * s4 + e) + lk - P / 2);
-                const float a = conv[(size_t)row * G.CS + col];
+                const double a = (double)conv[(size_t)row * G.CS + col];
 #pragma unroll
-                for (int ab = 0; ab < WB; ++ab) acc[ab] = rt::mfma_16x16x4(a, kb[ab][e], acc[ab]);
+                for (int ab = 0; ab < WB; ++ab)
+                    acc[ab] = rt::mfma_f64_16x16x4(a, kty[((size_t)ab * 64 * NQ + s4) * 4 + e], acc[ab]);
             }
         }
-        f32x4 ka[WB];
-#pragma unroll
-        for (int bb = 0; bb < WB; ++bb) ka[bb] = ktx[(size_t)bb * 64 * NQ + TPW * wave + t];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int bb = 0; bb < WB; ++bb)
+            for (int bb = 0; bb < WB; ++bb) {
+                const double ka = ktx[((size_t)bb * 64 * NQ + TPW * wave + t) * 4 + r];
 #pragma unroll
                 for (int ab = 0; ab < WB; ++ab)
-                    f[bb][ab] = rt::mfma_16x16x4(ka[bb][r], acc[ab][r], f[bb][ab]);
+                    f[bb][ab] = rt::mfma_f64_16x16x4(ka, acc[ab][r], f[bb][ab]);
+            }
     }
 #pragma unroll
     for (int bb = 0; bb < WB; ++bb)
@@ -350,7 +349,7 @@ SPX_DEVICE void fine_window_big(unsigned char* lds, const BigGeom& G, const floa
         for (int ab = 0; ab < WB; ++ab)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                fbuf[(bb * 16 + 4 * lk + r) * W + ab * 16 + lj] = f[bb][ab][r];
+                fbuf[(bb * 16 + lk + 4 * r) * W + ab * 16 + lj] = (float)f[bb][ab][r];
     rt::block_sync_lds();
 }
 
@@ -385,7 +384,7 @@ SPX_DEVICE void load_twiddles_big(unsigned char* lds, const cf* __restrict__ tw_
 template <int WB, typename TIn>
 SPX_TKERNEL(256) void pair_big_kernel(const TIn* __restrict__ ref, const TIn* __restrict__ img,
                                       int64_t nbatch, int ny, int nx, int U, int cc_type, int C,
-                                      const cf* __restrict__ tw_g, const float* __restrict__ ktab,
+                                      const cf* __restrict__ tw_g, const double* __restrict__ ktab,
                                       double* __restrict__ out, int* __restrict__ status,
                                       float* __restrict__ workspace) {
     typedef LdsGen L;

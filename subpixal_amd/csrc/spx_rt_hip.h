@@ -10,6 +10,7 @@ namespace rt {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 #define SPX_DEVICE __device__ __forceinline__
 #define SPX_KERNEL(nthreads) extern "C" __global__ __launch_bounds__(nthreads)
@@ -191,6 +192,12 @@ SPX_DEVICE double read_lane(double v, int lane) {
 // D[row=4*(l>>4)+r][col=l&15] in register r.  Exact f32 fma chain over k.
 SPX_DEVICE f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// v_mfma_f64_16x16x4_f64: A/B as the f32 form (one f64 per lane), but D[row=(l>>4)+4*r][col=l&15]
+// in register r (cdna_hip_programming.md: the f64 MFMA does not use the f32 C/D map).
+SPX_DEVICE f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
 }  // namespace rt

@@ -120,5 +120,27 @@ inline std::vector<float> make_ktab_big(int P, int U, int W) {
 }
 inline std::vector<float> make_ktab256(int U, int W) { return make_ktab_big(256, U, W); }
 
+// The same tables in float64 for the float64-accumulating refine stage of the paths above 85 px
+// (fine_window128 / fine_window_big use v_mfma_f64_16x16x4_f64).  Part [1] follows that
+// instruction's C/D map (row = lk + 4 r instead of 4 lk + r):
+//   [1][blk][lane][4 T + r] = K(-(16 blk + lj - W/2)/U - (CW w + TPW (lk + 4 r) + t - P/2))
+inline std::vector<double> make_ktab_big_f64(int P, int U, int W) {
+    const int blocks = W / 16, n = P / 4;
+    std::vector<double> k((size_t)2 * blocks * 64 * n);
+    for (int which = 0; which < 2; ++which)
+        for (int blk = 0; blk < blocks; ++blk)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < n; ++i) {
+                    const int lk = lane >> 4, lj = lane & 15;
+                    const int cw = P / 4, tpw = cw / 16;
+                    const int T = i >> 2, r = i & 3, w = T / tpw, tt = T % tpw;
+                    const int m = which == 0 ? (4 * i + lk - P / 2)
+                                             : (cw * w + tpw * (lk + 4 * r) + tt - P / 2);
+                    const double t = -(double)(16 * blk + lj - W / 2) / (double)U - (double)m;
+                    k[(((size_t)which * blocks + blk) * 64 + lane) * n + i] = kernel_big(P, t);
+                }
+    return k;
+}
+
 }  // namespace host
 }  // namespace spx

@@ -63,10 +63,10 @@ static int emu_pair_big(const TIn* ref, const TIn* img, int64_t nbatch, int ny, 
                         int cc_type, double* out, int* status) {
     const int wb = host::window_blocks(U);
     std::vector<float> tw = host::make_twiddles(64 * C);
-    std::vector<float> kt;
-    if (wb > 0) kt = host::make_ktab_big(64 * C, U, 16 * wb);
+    std::vector<double> kt;
+    if (wb > 0) kt = host::make_ktab_big_f64(64 * C, U, 16 * wb);
     const cf* twp = reinterpret_cast<const cf*>(tw.data());
-    const float* ktp = kt.empty() ? nullptr : kt.data();
+    const double* ktp = kt.empty() ? nullptr : kt.data();
     const int64_t grid = g_grid > 0 && g_grid < nbatch ? g_grid : nbatch;
     std::vector<float> ws((size_t)grid * (LdsBig<C>::kWsBytes / sizeof(float)));
     float* wsp = ws.data();
@@ -111,10 +111,10 @@ static int emu_pair_general(const TIn* ref, const TIn* img, int64_t nbatch, int 
     const int C = big_class_count(ny, nx);
     if (C > kBigMaxC) return -1;
     std::vector<float> tw = host::make_twiddles(64 * C);
-    std::vector<float> kt;
-    if (wb > 0) kt = host::make_ktab_big(64 * C, U, 16 * wb);
+    std::vector<double> kt;
+    if (wb > 0) kt = host::make_ktab_big_f64(64 * C, U, 16 * wb);
     const cf* twp = reinterpret_cast<const cf*>(tw.data());
-    const float* ktp = kt.empty() ? nullptr : kt.data();
+    const double* ktp = kt.empty() ? nullptr : kt.data();
     const int64_t grid = g_grid > 0 && g_grid < nbatch ? g_grid : nbatch;
     std::vector<float> ws((size_t)grid * big_ws_floats(C));
     float* wsp = ws.data();

@@ -22,6 +22,7 @@ namespace rt {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 #define SPX_DEVICE inline __attribute__((always_inline))
 #define SPX_KERNEL(nthreads) extern "C"
@@ -35,6 +36,7 @@ struct WaveState {
     float fb[64];
     int ia[64];
     double da[64];
+    double db[64];
 };
 
 struct EmuState {
@@ -153,6 +155,26 @@ SPX_DEVICE f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
         float acc = c[r];
         for (int k = 0; k < 4; ++k)
             acc = std::fmaf(w.fa[k * 16 + row], w.fb[k * 16 + col], acc);
+        d[r] = acc;
+    }
+    w.bar->arrive_and_wait();
+    return d;
+}
+
+// v_mfma_f64_16x16x4_f64: same A/B lane map, D[row=(l>>4)+4*r][col=l&15]; k-ordered fma chain.
+SPX_DEVICE f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
+    WaveState& w = my_wave();
+    int lane = ctx().tid & 63;
+    w.da[lane] = a;
+    w.db[lane] = b;
+    w.bar->arrive_and_wait();
+    int col = lane & 15;
+    f64x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = (lane >> 4) + 4 * r;
+        double acc = c[r];
+        for (int k = 0; k < 4; ++k)
+            acc = std::fma(w.da[k * 16 + row], w.db[k * 16 + col], acc);
         d[r] = acc;
     }
     w.bar->arrive_and_wait();

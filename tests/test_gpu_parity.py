@@ -42,7 +42,7 @@ def test_pair_mode_vs_oracle_n64(spx, up, tol):
         assert np.max(np.abs(got - truth)) < 1e-3
 
 
-@pytest.mark.parametrize('up,tol', [(1, 1e-5), (2, 2e-5), (20, 5e-4)])   # float32 noise on the 20x finer grid
+@pytest.mark.parametrize('up,tol', [(1, 1e-5), (2, 2e-5), (20, 1e-4), (40, 1e-4)])   # refine stage accumulates in float64 above 85 px
 def test_pair_mode_vs_oracle_n128(spx, up, tol):
     """BASELINE config 3 shape: 128x128 cutouts (FFT period 192 = the smallest alias-free
     period for the 'same' window, 9 spectral classes, per-workgroup workspace), upsample=20."""
@@ -55,7 +55,7 @@ def test_pair_mode_vs_oracle_n128(spx, up, tol):
         assert np.max(np.abs(got - truth)) < 1e-3
 
 
-@pytest.mark.parametrize('up,tol', [(1, 1e-5), (2, 2e-5), (10, 2e-4), (20, 5e-4)])
+@pytest.mark.parametrize('up,tol', [(1, 1e-5), (2, 2e-5), (10, 1e-4), (20, 1e-4)])
 def test_pair_mode_vs_oracle_n96(spx, up, tol):
     """86..96 px on the period-192 path: GPU vs oracle"""
     ref, img, truth = datagen.pair_batch(11, 12, 96)
@@ -116,7 +116,7 @@ def test_general_path_above_128_px(spx):
             got, st = spx.xcorr_refine_batch(ref, img, upsample=up, cc_type=name, return_status=True)
             exp, est = orc.xcorr_refine_batch(ref, img, up, name)
             assert np.array_equal(st, est), (ny, nx, up)
-            assert np.max(np.abs(got - exp)) < (1e-3 if up > 1 else 3e-5), (ny, nx, up, np.max(np.abs(got - exp)))
+            assert np.max(np.abs(got - exp)) < (3e-4 if up > 1 else 3e-5), (ny, nx, up, np.max(np.abs(got - exp)))
     r5, im4, _ = datagen.dither_batch(5, 3, 160)
     for dt in (np.float32, np.float64):
         d, icc, st = spx.find_displacement_batch(r5.astype(dt), im4.astype(dt), cc_type='ZNCC',
@@ -189,9 +189,7 @@ def test_float64_inputs(spx):
                 got, st = spx.xcorr_refine_batch(ref, img, upsample=up, cc_type=name, return_status=True)
                 exp, est = orc.xcorr_refine_batch(ref, img, up, name)
                 assert np.array_equal(st, est)
-                # (float32 transform noise on a flat fine grid grows with the spot: 128 px cutouts hold
-                #  sigma ~ 10 px spots here; north_star asks for 1e-3)
-                assert np.max(np.abs(got - exp)) < (2e-4 if n <= 85 else 4e-4), (n, name, up)
+                assert np.max(np.abs(got - exp)) < 2e-4, (n, name, up)
 
 
 def test_pair_mode_u1_vs_reference_goldens(spx, golden_dir):
@@ -247,7 +245,7 @@ def test_pair_mode_shapes_cc_types_and_zeros(spx):
                                                  return_status=True)
                 oname = name.upper() if name.upper() in ('NCC', 'ZNCC') else 'CC'
                 exp, est = orc.xcorr_refine_batch(ref, img, up, oname)
-                assert np.max(np.abs(got - exp)) < (2e-4 if max(ny, nx) <= 85 else 4e-4), (ny, nx, name, up)
+                assert np.max(np.abs(got - exp)) < 2e-4, (ny, nx, name, up)
                 assert np.array_equal(st, est)
 
 

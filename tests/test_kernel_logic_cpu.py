@@ -355,7 +355,7 @@ def test_general_path_above_128_px():
             got, st = emu.pair(r[None], i[None], up, code)
             s2 = []
             e = orc.xcorr_refine(r, i, up, name, _status=s2)
-            assert np.max(np.abs(got[0] - np.array(e))) < (4e-4 if up > 1 else 2e-5), (ny, nx, up)
+            assert np.max(np.abs(got[0] - np.array(e))) < (1e-4 if up > 1 else 2e-5), (ny, nx, up)
             assert st[0] == s2[-1]
     r5, m4, _ = datagen.dither_batch(3, 1, 150)
     d, st, icc = emu.disp5(r5, m4, 1)
