@@ -1298,11 +1298,13 @@ SPX_DEVICE void pair_body(const TIn* __restrict__ ref, const TIn* __restrict__ i
             const bool okx = (x1 >= fx0 && x1 + 4 < fx0 + W) || imax == 0;
             const bool oky = (y1 >= fy0 && y1 + 4 < fy0 + W) || jmax == 0;
             if (okx && oky) { inside = true; break; }
-            // move the window centre one coarse pixel towards the peak and redo
+            // move the window centre one coarse pixel towards the peak and redo.  The centre may
+            // sit ONE PAST the last coarse sample (q = n): the fine image extends (U-1)/U of a pixel
+            // beyond it, and a peak in that strip is bracketed from there.
             if (!okx) qxc += (b < W / 2) ? -1 : 1;
             if (!oky) qyc += (a < W / 2) ? -1 : 1;
-            qxc = qxc < 0 ? 0 : (qxc > nx - 1 ? nx - 1 : qxc);
-            qyc = qyc < 0 ? 0 : (qyc > ny - 1 ? ny - 1 : qyc);
+            qxc = qxc < 0 ? 0 : (qxc > nx ? nx : qxc);
+            qyc = qyc < 0 ? 0 : (qyc > ny ? ny : qyc);
             rt::block_sync_lds();      // every wave is done with this window before it is rebuilt
         }
         clk.tick(16);

@@ -403,8 +403,8 @@ SPX_DEVICE void fine_window128(unsigned char* lds, const double* __restrict__ kt
     const int lk = lane >> 4, lj = lane & 15;
     float* fbuf = reinterpret_cast<float*>(lds + L::FB_OFF) + wave * W * W;
     // (window centre clamped into the cutout: a corrupted index must not become an address)
-    qyc = qyc < 0 ? 0 : (qyc > ny - 1 ? ny - 1 : qyc);
-    qxc = qxc < 0 ? 0 : (qxc > nx - 1 ? nx - 1 : qxc);
+    qyc = qyc < 0 ? 0 : (qyc > ny ? ny : qyc);
+    qxc = qxc < 0 ? 0 : (qxc > nx ? nx : qxc);
     const int lyc = conv_index(ny, qyc), lxc = conv_index(nx, qxc);
     ktab = rt::launder(ktab);
     const F64x2* kty = reinterpret_cast<const F64x2*>(ktab) + (size_t)lane * NQ * 2;
@@ -540,8 +540,8 @@ SPX_DEVICE void pair128_body(const TIn* __restrict__ ref, const TIn* __restrict_
             if (okx && oky) { inside = true; break; }
             if (!okx) qxc += (b < W / 2) ? -1 : 1;
             if (!oky) qyc += (a < W / 2) ? -1 : 1;
-            qxc = qxc < 0 ? 0 : (qxc > nx - 1 ? nx - 1 : qxc);
-            qyc = qyc < 0 ? 0 : (qyc > ny - 1 ? ny - 1 : qyc);
+            qxc = qxc < 0 ? 0 : (qxc > nx ? nx : qxc);
+            qyc = qyc < 0 ? 0 : (qyc > ny ? ny : qyc);
             rt::block_sync_lds();       // everyone has read the window before it is rebuilt
         }
         if (inside) {

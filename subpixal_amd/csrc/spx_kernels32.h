@@ -417,8 +417,8 @@ SPX_DEVICE void pair32_wave(const cf* tw, float* wbuf, double* fit, const TIn* _
             if (okx && oky) { inside = true; break; }
             if (!okx) qxc += (b < W / 2) ? -1 : 1;
             if (!oky) qyc += (a < W / 2) ? -1 : 1;
-            qxc = qxc < 0 ? 0 : (qxc > nx - 1 ? nx - 1 : qxc);
-            qyc = qyc < 0 ? 0 : (qyc > ny - 1 ? ny - 1 : qyc);
+            qxc = qxc < 0 ? 0 : (qxc > nx ? nx : qxc);
+            qyc = qyc < 0 ? 0 : (qyc > ny ? ny : qyc);
             rt::wave_sync();
         }
         if (inside) {

@@ -308,8 +308,8 @@ SPX_DEVICE void fine_window_big(unsigned char* lds, const BigGeom& G, const doub
     const int wave = tid >> 6, lane = tid & 63;
     const int lk = lane >> 4, lj = lane & 15;
     float* fbuf = reinterpret_cast<float*>(lds + LdsGen::FB_OFF) + wave * W * W;
-    qyc = qyc < 0 ? 0 : (qyc > ny - 1 ? ny - 1 : qyc);
-    qxc = qxc < 0 ? 0 : (qxc > nx - 1 ? nx - 1 : qxc);
+    qyc = qyc < 0 ? 0 : (qyc > ny ? ny : qyc);
+    qxc = qxc < 0 ? 0 : (qxc > nx ? nx : qxc);
     const int lyc = conv_index(ny, qyc), lxc = conv_index(nx, qxc);
     const double* kty = ktab + (size_t)lane * NQ * 4;
     const double* ktx = ktab + ((size_t)WB * 64 + lane) * NQ * 4;
@@ -448,8 +448,8 @@ SPX_TKERNEL(256) void pair_big_kernel(const TIn* __restrict__ ref, const TIn* __
                 if (okx && oky) { inside = true; break; }
                 if (!okx) qxc += (b < W / 2) ? -1 : 1;
                 if (!oky) qyc += (a < W / 2) ? -1 : 1;
-                qxc = qxc < 0 ? 0 : (qxc > nx - 1 ? nx - 1 : qxc);
-                qyc = qyc < 0 ? 0 : (qyc > ny - 1 ? ny - 1 : qyc);
+                qxc = qxc < 0 ? 0 : (qxc > nx ? nx : qxc);
+                qyc = qyc < 0 ? 0 : (qyc > ny ? ny : qyc);
                 rt::block_sync_lds();
             }
             if (inside) {

@@ -278,6 +278,27 @@ def test_pair_mode_edge_cases(spx):
     assert st[0] == 1 and st[2] == 1          # SPX_ST_EDGE
 
 
+def test_peak_beyond_the_last_coarse_sample(spx):
+    """The fine image extends (U-1)/U of a pixel beyond the last coarse sample of the 'same' window;
+    a peak there (shift n//2 + 0.8 px) used to end in SPX_ST_WINDOW with an integer result.  The
+    refinement window may now be centred one past the last sample: same answer as the oracle's full
+    fine grid, status 0, for every kernel family and several window sizes (the
+    ST_WINDOW branch was untested; it is now reachable only by non-band-limited pathologies)."""
+    for n, x0 in ((20, 4.0), (64, 12.0), (80, 14.0), (100, 20.0), (150, 30.0)):
+        ref = datagen.spot(n, n, x0, (n - 1) / 2, 2.5).astype(np.float32)
+        img = datagen.spot(n, n, x0 + n // 2 + 0.8, (n - 1) / 2 + 0.3, 2.5).astype(np.float32)
+        pairs_r = np.stack([ref, ref.T.copy()])
+        pairs_i = np.stack([img, img.T.copy()])
+        for up in (3, 10, 20, 33):
+            got, st = spx.xcorr_refine_batch(pairs_r, pairs_i, upsample=up, return_status=True)
+            for k in range(2):
+                s2 = []
+                e = orc.xcorr_refine(pairs_r[k], pairs_i[k], up, 'CC', _status=s2,
+                                     full_grid=(n * up <= 1500) or None)
+                assert st[k] == s2[-1] == 0, (n, up, st, s2)
+                assert np.max(np.abs(got[k] - np.array(e))) < 3e-4, (n, up, got[k], e)
+
+
 def test_shape_and_upsample_limits(spx):
     from subpixal_amd._ffi import SubpixalHipError
     a = np.zeros((2, 683, 64), np.float32)

@@ -363,3 +363,21 @@ def test_general_path_above_128_px():
     assert np.abs(d - e).max() < 2e-5 and np.array_equal(st, est)
     eicc = orc.build_icc(r5[0], *m4[0], cc_type='NCC')[0]
     assert np.abs(icc[0] - eicc).max() < 3e-6 * np.abs(eicc).max()
+
+
+def test_peak_beyond_the_last_coarse_sample_is_bracketed():
+    """the SPX_ST_WINDOW branch was untested.  The one way to reach it was a peak in the
+    strip of the fine image that extends (U-1)/U of a pixel beyond the last coarse sample (shift
+    n//2 + 0.8 px): the window could not move past the last sample and gave up after four tries with
+    an integer peak, where the oracle (full fine grid) fits normally.  The window centre may now sit
+    one past the last sample; kernel == oracle there, status 0, on every kernel family."""
+    for n, x0 in ((64, 12.0), (32, 6.0), (80, 14.0), (100, 20.0)):
+        ref = datagen.spot(n, n, x0, (n - 1) / 2, 2.5).astype(np.float32)
+        img = datagen.spot(n, n, x0 + n // 2 + 0.8, (n - 1) / 2 + 0.3, 2.5).astype(np.float32)
+        for r, i in ((ref, img), (ref.T.copy(), img.T.copy())):
+            got, st = emu.pair(r[None], i[None], 10, 0)
+            s2 = []
+            e = orc.xcorr_refine(r, i, 10, 'CC', _status=s2, full_grid=True)
+            assert st[0] == s2[-1] == 0, (n, st, s2)
+            assert np.max(np.abs(got[0] - np.array(e))) < 1e-4, (n, got, e)
+            assert max(got[0]) > n // 2 + 0.7
