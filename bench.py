@@ -136,9 +136,12 @@ def cpu_baseline(tile=TILE, upsample=UPSAMPLE, n_u10=1200, n_u1=3000, n_ref=2000
 # ---------------------------------------------------------------------------
 F32_PEAK_TFLOPS = 157.3
 FLOPS_PER_PAIR = {          # (kernel family, refinement-window blocks) -> (vector, matrix) MFLOP
-    ('64', 1): (2.086, 0.655),
+    ('32', 1): (0.407, 0.197),
+    ('64', 1): (2.090, 0.655),
     ('64fold', 1): (2.157, 0.655),
-    ('192', 2): (5.9, 2.75),
+    # period 192: 9 class transforms (3 rounds of the loop body) + folds + combine, analytic
+    # (DESIGN.md section 5); its 1344 refine MFMAs per pair are v_mfma_f64_16x16x4_f64
+    ('192', 2): (4.7, 2.75),
 }
 
 

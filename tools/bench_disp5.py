@@ -5,10 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 import subpixal_amd, datagen
-N = int(os.environ.get('N', 20000))
-for n in (32, 64, 96, 128):
+N = int(os.environ.get("N", 20000))
+for n in (32, 64, 80, 96, 128, 160):
     ref, im4, truth = datagen.dither_batch(3, 64, n)
-    reps = N // 64
+    reps = (N if n <= 128 else N // 8) // 64
     r = torch.from_numpy(ref).cuda().repeat(reps, 1, 1).contiguous()
     m = torch.from_numpy(im4).cuda().repeat(reps, 1, 1, 1).contiguous()
     for cc in ('CC', 'NCC', 'ZNCC'):
