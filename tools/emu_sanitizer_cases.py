@@ -17,12 +17,17 @@ from oracle import subpixal_oracle as orc              # noqa: E402
 quick = '--quick' in sys.argv          # thread sanitizer: 10-20x slower, fewer window sizes
 cases = [(64, 6, 2, (1, 10) if quick else (1, 2, 10, 16, 20, 30, 43, 59)),
          (50, 2, 1, () if quick else (27,)),
+         (63, 2, 1, () if quick else (10,)),                      # ragged rows: shifted chunk loads
          (32, 10, 1, (10,) if quick else (1, 10, 20, 43)),
          (21, 5, 1, () if quick else (59,)),
-         (96, 2, 1, (10,) if quick else (1, 2, 10, 27)),
-         (70, 1, 1, () if quick else (43,)),
+         (70, 3, 1, (10,) if quick else (1, 10, 43)),             # 64 tile, fold path
+         (85, 2, 1, () if quick else (2, 27)),
+         (65, 1, 1, () if quick else (59,)),
+         (96, 2, 1, (10,) if quick else (1, 2, 10, 27)),          # period 192
          (128, 2, 1, (2,) if quick else (1, 11, 20, 43)),
-         (97, 1, 1, () if quick else (59,))]
+         (97, 1, 1, () if quick else (59,)),
+         (150, 1, 1, () if quick else (1, 10)),                   # general path
+         (131, 1, 1, () if quick else (30,))]
 for n, count, grid, ups in cases:
     ref, img, truth = datagen.pair_batch(7, count, n)
     for up in ups:
@@ -35,7 +40,19 @@ for n, count, grid, ups in cases:
         err = float(np.abs(got - exp).max())
         print('pair %3dx%-3d U=%-2d max |d| %.2e' % (n, n, up, err), flush=True)
         assert np.array_equal(st, est) and err < 2e-3
-for n in (24, 48) if quick else (24, 48, 100):
+# non-finite pixels and float64 inputs on every family
+for n in (20, 64, 80, 100) if not quick else (64,):
+    ref, img, truth = datagen.pair_batch(9, 2, n)
+    img = img.copy()
+    img[0, 3, 4] = np.nan
+    for up in (1, 10):
+        got, st = emu.pair(ref, img, up)
+        assert st[0] == 6 and st[1] == 0
+    got, st = emu.pair(ref.astype(np.float64), datagen.pair_batch(9, 2, n)[1].astype(np.float64), 10, 2)
+    exp, est = orc.xcorr_refine_batch(ref.astype(np.float64), datagen.pair_batch(9, 2, n)[1].astype(np.float64), 10, 'ZNCC')
+    print('nan/f64 %3d ok, f64 ZNCC max |d| %.2e' % (n, float(np.abs(got - exp).max())), flush=True)
+    assert np.array_equal(st, est) and np.abs(got - exp).max() < 1e-3
+for n in (24, 48) if quick else (24, 48, 77, 100, 140):
     r, m4, t = datagen.dither_batch(3, 2, n)
     d, icc, st = emu.disp5(r, m4, 1)
     e, est = orc.find_displacement_batch(r, m4, 'NCC')
