@@ -111,7 +111,7 @@ const char* spx_last_error(void);
  * ones (period 192, up to 128 px) keep per-workgroup class planes and the full convolution in a
  * workspace of 435 KiB per resident workgroup (independent of nbatch beyond the grid); the
  * general path (129..682 px, period 64 C with C = 4..16 classes per axis) needs
- * (4 C^2 64^2 + P (P + 4)) floats per workgroup, one workgroup per CU.
+ * (4 C^2 64^2 + P (P + 4)) floats per workgroup, two workgroups per CU (one above 341 px).
  * For the reference mode `need_icc` adds room for the interlaced images when the
  * caller does not want them back (out_icc == NULL).
  */

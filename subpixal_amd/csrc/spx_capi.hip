@@ -147,8 +147,12 @@ int big_tables_for(DeviceTables* t, int C, int upsample, const spx::cf** tw, con
     }
     return 0;
 }
-// one workgroup per CU there: its workspace is megabytes (4 C^2 planes + the P x P convolution)
-int64_t grid_general(int num_cu, int64_t nbatch) { return nbatch < num_cu ? nbatch : num_cu; }
+// two resident workgroups per CU (as the period-192 path) up to C = 8, one above: the workspace
+// of a workgroup is megabytes there (4 C^2 planes + the P x P convolution: 21 MB at C = 16)
+int64_t grid_general(int num_cu, int64_t nbatch, int C) {
+    const int64_t cap = (int64_t)num_cu * (C <= 8 ? 2 : 1);
+    return nbatch < cap ? nbatch : cap;
+}
 
 // workgroups of a period-192 launch (each owns one workspace slot)
 int64_t grid_big(int num_cu, int64_t nbatch) {
@@ -309,9 +313,10 @@ int run_disp5(DeviceTables* t, Tile tile, bool fold, const TIn* ref, const TIn* 
 size_t ws_bytes_xcorr(int64_t nbatch, int ny, int nx) {
     if (nbatch <= 0 || ny <= 0 || nx <= 0) return 0;
     const Tile tile = tile_for(ny, nx);
-    if (tile == TILE_BIG)
-        return (size_t)grid_general(device_cus(), nbatch) * spx::big_ws_floats(spx::big_class_count(ny, nx)) *
-               sizeof(float);
+    if (tile == TILE_BIG) {
+        const int C = spx::big_class_count(ny, nx);
+        return (size_t)grid_general(device_cus(), nbatch, C) * spx::big_ws_floats(C) * sizeof(float);
+    }
     if (tile != TILE192) return 0;
     return (size_t)grid_big(device_cus(), nbatch) * spx::kWs96Bytes;
 }
@@ -323,7 +328,7 @@ int run_pair_general(DeviceTables* t, const TIn* ref, const TIn* img, const Pair
     auto kern = spx::pair_big_kernel<WB, TIn>;
     int rc = allow_lds(t, kern, lds);
     if (rc || !launch) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid_general(t->num_cu, a.nbatch)), dim3(spx::kThreads), lds,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid_general(t->num_cu, a.nbatch, C)), dim3(spx::kThreads), lds,
                        a.s, ref, img, a.nbatch, a.ny, a.nx, a.U, a.cc_type, C, tw,
                        reinterpret_cast<const double*>(a.ktab), a.out, a.status, a.ws);
     SPX_HIP(hipGetLastError());
@@ -347,7 +352,7 @@ int run_disp5_general(DeviceTables* t, const TIn* ref, const TIn* im4, const Dis
     auto kern = spx::disp5_big_kernel<TIn>;
     int rc = allow_lds(t, kern, lds);
     if (rc || !launch) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid_general(t->num_cu, a.nbatch)), dim3(spx::kThreads), lds,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid_general(t->num_cu, a.nbatch, C)), dim3(spx::kThreads), lds,
                        a.s, ref, im4, a.nbatch, a.ny, a.nx, a.cc_type, C, tw, a.icc, a.out, a.status, a.ws);
     SPX_HIP(hipGetLastError());
     return 0;

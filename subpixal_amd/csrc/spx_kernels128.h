@@ -229,21 +229,38 @@ SPX_DEVICE void class_round128(unsigned char* lds, const TIn* __restrict__ ref,
     }
     clk.tick(2);
     // g_c -> workspace planes [class][re|im][64][64], through the wave's LDS buffer so the
-    // global stores are 16-byte, row-contiguous
+    // global stores are 16-byte, row-contiguous.  Two economies (C = 3):
+    //  * the real plane of class (0,0) is never written: its twiddle is 1 for every block, so
+    //    only Im g_00 reaches conv = Im(sum_c conj(w)^(c.s) g_c);
+    //  * the LAST round's planes stay on chip -- nothing overwrites the exchange region until the
+    //    combine has read them: each wave leaves its real plane in its own buffer, wave 0 parks
+    //    its imaginary plane in the idle fourth wave's buffer (4 of the 18 planes, 128 KiB of
+    //    workspace traffic per pair less); the other two imaginary planes go to the workspace.
+    const bool park = C == 3 && cy == C - 1;
+    if (park) rt::block_sync_lds();            // every wave is past its last transposition
     float* g = ws + (size_t)((cy * C + cx) * 2) * kWs128PlaneFloats;
 #pragma unroll
-    for (int part = 0; part < 2; ++part) {
+    for (int k = 0; k < 2; ++k) {
+        const int part = park ? 1 - k : k;     // parking: imaginary first, the real plane stays
+        const bool unused = C == 3 && cy == 0 && cx == 0 && part == 0;
+        if (unused || (park && !active)) continue;
 #pragma unroll
         for (int y1 = 0; y1 < 8; ++y1)
 #pragma unroll
             for (int x1 = 0; x1 < 8; ++x1)
                 xch[(l1 + 8 * y1) * 64 + l0 + 8 * x1] = part ? v[y1][x1].y : v[y1][x1].x;
         rt::wave_sync();
-        if (active) {
+        if (active && park && part == 1 && wave == 0) {      // LDS -> LDS: the idle wave's buffer
+            f32x4* dst = reinterpret_cast<f32x4*>(lds + L::R_OFF + 3 * L::XCH_WAVE_BYTES);
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                reinterpret_cast<f32x4*>(g + part * kWs128PlaneFloats)[i * 64 + lane] =
-                    reinterpret_cast<const f32x4*>(xch)[i * 64 + lane];
+                dst[i * 64 + lane] = reinterpret_cast<const f32x4*>(xch)[i * 64 + lane];
+        } else if (active && !(park && part == 0)) {
+            // (laundered: keeps the GLOBAL address space, or the two branches are merged into flat stores)
+            f32x4* dst = rt::launder_lanes(reinterpret_cast<f32x4*>(g + part * kWs128PlaneFloats));
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                dst[i * 64 + lane] = reinterpret_cast<const f32x4*>(xch)[i * 64 + lane];
         }
         rt::wave_sync();
     }
@@ -280,7 +297,8 @@ template <int C> SPX_DEVICE void class_dft(const cf (&a)[C], cf (&x)[C]) {
 //                            (bv, bi) ACCUMULATE the arg-max over the interlaced image (NaN ranked
 //                            as +inf, see nan_as_inf).
 template <int C, int MODE>
-SPX_DEVICE void combine128(const float* __restrict__ ws, float* __restrict__ conv, float out_scale,
+SPX_DEVICE void combine128(const unsigned char* lds, const float* __restrict__ ws,
+                           float* __restrict__ conv, float out_scale,
                            int ny, int nx, float* __restrict__ icc, int ox, int oy, float& bv, int& bi) {
     typedef LdsBig<C> L;
     const int tid = fresh_tid();
@@ -291,8 +309,20 @@ SPX_DEVICE void combine128(const float* __restrict__ ws, float* __restrict__ con
         f32x4 gre[C * C], gim[C * C];
 #pragma unroll
         for (int c = 0; c < C * C; ++c) {
-            gre[c] = reinterpret_cast<const f32x4*>(ws + (size_t)(c * 2) * kWs128PlaneFloats)[i4];
-            gim[c] = reinterpret_cast<const f32x4*>(ws + (size_t)(c * 2 + 1) * kWs128PlaneFloats)[i4];
+            // C = 3: planes of the last round that class_round128 left in LDS (real planes in the
+            // waves' own buffers, the imaginary plane of class (2,0) in the fourth buffer); the real
+            // plane of class (0,0) does not exist (it cannot reach the imaginary part of the sum)
+            // (separate statements per address space: a pointer chosen by ?: would be a generic one)
+            if (C == 3 && c == 0)
+                gre[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            else if (C == 3 && c >= C * (C - 1))
+                gre[c] = reinterpret_cast<const f32x4*>(lds + L::R_OFF + (c - C * (C - 1)) * L::XCH_WAVE_BYTES)[i4];
+            else
+                gre[c] = reinterpret_cast<const f32x4*>(ws + (size_t)(c * 2) * kWs128PlaneFloats)[i4];
+            if (C == 3 && c == C * (C - 1))
+                gim[c] = reinterpret_cast<const f32x4*>(lds + L::R_OFF + 3 * L::XCH_WAVE_BYTES)[i4];
+            else
+                gim[c] = reinterpret_cast<const f32x4*>(ws + (size_t)(c * 2 + 1) * kWs128PlaneFloats)[i4];
         }
         const int ly = i4 >> 4, lx = (i4 & 15) << 2;
         f32x4 o[C][C];                                               // [sy][sx]
@@ -362,7 +392,7 @@ SPX_DEVICE void conv_full128(unsigned char* lds, const TIn* __restrict__ ref,
     rt::block_sync();                    // class planes (global) visible to every wave
     // conv = Im(IFFT(Z^2)) / 2, IFFT normalisation 1/P^2, balance undone
     const float out_scale = 0.5f / ((float)(L::P) * (float)(L::P) * bal);
-    combine128<C, MODE>(ws, ws + L::kConvOffsetFloats, out_scale, ny, nx, icc, ox, oy, bv, bi);
+    combine128<C, MODE>(lds, ws, ws + L::kConvOffsetFloats, out_scale, ny, nx, icc, ox, oy, bv, bi);
     rt::block_sync();
     clk.tick(4);
 }

@@ -57,6 +57,14 @@ template <typename T> SPX_DEVICE T* launder(T* p) {
     return (T*)g;
 }
 
+// same for a pointer that lives in vector registers (derived from the work-item id)
+template <typename T> SPX_DEVICE T* launder_lanes(T* p) {
+    typedef T __attribute__((address_space(1)))* global_ptr;
+    global_ptr g = (global_ptr)p;
+    asm volatile("" : "+v"(g));
+    return (T*)g;
+}
+
 SPX_DEVICE int launder_uniform(int v) {
     asm volatile("" : "+s"(v));
     return v;

@@ -72,6 +72,7 @@ SPX_DEVICE void wave_sync() { my_wave().bar->arrive_and_wait(); }
 SPX_DEVICE void wave_sync_mem() { my_wave().bar->arrive_and_wait(); }
 
 template <typename T> SPX_DEVICE T* launder(T* p) { return p; }
+template <typename T> SPX_DEVICE T* launder_lanes(T* p) { return p; }
 SPX_DEVICE int launder_lane(int v) { return v; }
 SPX_DEVICE int launder_uniform(int v) { return v; }
 SPX_DEVICE unsigned long long clock_stamp() { return 0; }
