@@ -296,7 +296,9 @@ def test_peak_beyond_the_last_coarse_sample(spx):
                 s2 = []
                 e = orc.xcorr_refine(pairs_r[k], pairs_i[k], up, 'CC', _status=s2,
                                      full_grid=(n * up <= 1500) or None)
-                assert st[k] == s2[-1] == 0, (n, up, st, s2)
+                # same outcome as the oracle's full fine grid (at upsample 3 the vertex can fall beyond
+                # the image end: status 3 on both sides); never the give-up status of the window logic
+                assert st[k] == s2[-1] and st[k] != 4, (n, up, st, s2)
                 assert np.max(np.abs(got[k] - np.array(e))) < 3e-4, (n, up, got[k], e)
 
 
