@@ -474,7 +474,9 @@ SPX_TKERNEL(256) void disp5_32_kernel(const TIn* __restrict__ ref, const TIn* __
     typedef Lds32 L;
     SPX_DYN_LDS(lds);
     load_twiddles32(lds, tw_g);
-    const int wave = rt::thread_id() >> 6;
+    // the wave index as a SCALAR: the per-source pointers and statistics derived from it then live in
+    // scalar registers across the four dithers instead of occupying (and spilling) vector ones
+    const int wave = rt::read_lane(rt::thread_id() >> 6, 0);
     const cf* tw = reinterpret_cast<const cf*>(lds + L::TW_OFF);
     float* wbuf = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::wave_bytes(16));
     double* fit = reinterpret_cast<double*>(lds + L::SCR_OFF + wave * 256);
@@ -485,7 +487,11 @@ SPX_TKERNEL(256) void disp5_32_kernel(const TIn* __restrict__ ref, const TIn* __
         const TIn* r = ref + p * stride;
         const TIn* m4 = im4 + 4 * p * stride;
         float* icc = icc_all + 4 * p * stride;
-        const NormStatsT<TIn> ns = norm_stats_wave(r, m4, 4, stride, ny * nx, cc_type);
+        NormStatsT<TIn> ns = norm_stats_wave(r, m4, 4, stride, ny * nx, cc_type);
+        ns.im_mean = rt::read_lane(ns.im_mean, 0);          // wave-uniform values -> scalar registers
+        ns.im_std = rt::read_lane(ns.im_std, 0);
+        ns.ref_mean = rt::read_lane(ns.ref_mean, 0);
+        ns.ref_std = rt::read_lane(ns.ref_std, 0);
         float bv = -__builtin_inff();
         int bi = 0x7fffffff;
         for (int q = 0; q < 4; ++q) {

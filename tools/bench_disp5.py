@@ -6,12 +6,14 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 import subpixal_amd, datagen
 N = int(os.environ.get("N", 20000))
-for n in (32, 64, 80, 96, 128, 160):
+SIZES = [int(v) for v in os.environ.get('SIZES', '32,64,80,96,128,160').split(',')]
+TYPES = os.environ.get('CC_TYPES', 'CC,NCC,ZNCC').split(',')
+for n in SIZES:
     ref, im4, truth = datagen.dither_batch(3, 64, n)
     reps = (N if n <= 128 else N // 8) // 64
     r = torch.from_numpy(ref).cuda().repeat(reps, 1, 1).contiguous()
     m = torch.from_numpy(im4).cuda().repeat(reps, 1, 1, 1).contiguous()
-    for cc in ('CC', 'NCC', 'ZNCC'):
+    for cc in TYPES:
         subpixal_amd.find_displacement_batch(r, m, cc_type=cc)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(3):

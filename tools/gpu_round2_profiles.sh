@@ -17,8 +17,13 @@ echo "== PMC traffic"
 for cfg in "64 10" "128 20" "80 10" "96 10"; do set -- $cfg
   timeout -k 10 400 bash tools/gpu_pmc.sh $1 $2 100000 > $O/pmc_$1.log 2>&1; grep -E "hbm_bytes|algorithmic" $O/pmc_$1.log
 done
+timeout -k 10 400 bash tools/gpu_pmc_disp5.sh 64 > $O/pmc_disp5_64.log 2>&1; grep -E "ratio|hbm_bytes" $O/pmc_disp5_64.log
 echo "== SQ counters (64 tile)"
 timeout -k 10 600 bash tools/gpu_sq.sh > $O/sq.log 2>&1; tail -2 $O/sq.log
+# (the traffic files just measured on this build, where bench.py looks for them)
+cp gpurun_out/pmc_traffic_64_u10.json profiles/r02/pmc_traffic.json; for t in "128_u20" "80_u10" "96_u10"; do cp gpurun_out/pmc_traffic_$t.json profiles/r02/; done
+timeout -k 10 300 python bench.py --steps 20 > $O/bench.json 2>$O/bench.err && cut -c1-200 $O/bench.json
+timeout -k 10 200 python bench.py --steps 10 --tile 128 --upsample 20 --no-cpu-baseline > $O/bench_128_u20.json 2>>$O/bench.err
 echo "== auxiliary"
 timeout -k 10 300 python tools/bench_shapes.py 2>&1 | grep -v amdgpu > $O/shapes.txt; cat $O/shapes.txt
 N=20000 timeout -k 10 300 python tools/bench_disp5.py 2>&1 | grep -v amdgpu > $O/disp5.txt; cat $O/disp5.txt
