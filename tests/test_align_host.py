@@ -83,3 +83,23 @@ def test_affine_from_map_and_shift_affine():
 
     fit2, res2 = blot.affine_from_map(distorted, (64, 48))
     assert 1e-4 < res2 < 1e-2 and np.allclose(fit2[[0, 1, 3, 4]], true[[0, 1, 3, 4]], atol=1e-3)
+
+
+def test_zero_weight_points_are_not_measurements():
+    """sources without a usable displacement (non-finite cutout, skipped shape) enter
+    the fit with zero weight; they must neither move the fit nor count in fitmask / rms."""
+    from subpixal_amd.align import usable_status, ST_SKIPPED
+    xy = _points(50, 3)
+    t = np.array([0.4, -0.2])
+    uv = xy + t
+    uv[[3, 17]] += 1e6                       # what a meaningless shift looks like
+    w = np.ones(50)
+    w[[3, 17]] = 0.0
+    fit = iter_linear_fit(xy, uv, wuv=w, fitgeom='general', nclip=3, sigma=3.0)
+    np.testing.assert_allclose(fit['offset'] + (fit['fit_matrix'] - np.eye(2)) @ xy.mean(0), t, atol=1e-6)
+    assert not fit['fitmask'][[3, 17]].any() and fit['fitmask'].sum() == 48
+    assert np.all(fit['rms'] < 1e-6)
+    with pytest.raises(ValueError, match="non-zero weight"):
+        iter_linear_fit(xy[:3], uv[:3], wuv=np.array([1.0, 0.0, 0.0]), fitgeom='general')
+    st = np.array([0, 1, 2, 3, 4, 5, 6, ST_SKIPPED])
+    assert list(usable_status(st)) == [True, True, True, True, False, False, False, False]

@@ -87,3 +87,39 @@ def test_find_linear_fit_with_blot_callable():
     assert len(blts) == 12 and 'irmse' in fit and fit['fitmask'].all()
     # grid displacement restored (align.py:679)
     assert all(ct.dx == 0 and ct.dy == 0 for ct in img_cutouts)
+
+
+def test_find_linear_fit_survives_bad_sources():
+    """a cutout with NaN fill (overhanging its frame) or one larger than the kernels
+    take used to poison / abort the whole fit.  They now come back flagged (status 6 / -1), get zero
+    weight, and the fit over the remaining sources is the fit without them."""
+    from subpixal_amd.align import find_linear_fit, ST_SKIPPED
+    rng = np.random.default_rng(4)
+    refs, blts, truth = [], [], []
+    for k in range(10):
+        n = (48, 64, 80)[k % 3]
+        tx, ty = rng.uniform(-1, 1, 2)
+        ims = datagen.dither_set(n, n, tx, ty, 3.0, 1.0, np.float32)
+        refs.append(ims[0])
+        blts.append(ims[1:])
+        truth.append((tx, ty))
+    good_fit, _, _ = find_linear_fit(refs, blts, fitgeom='shift', cc_type='NCC')
+    bad = refs[2].copy()
+    bad[:5, :] = np.nan                                       # NaN fill of an overhanging cutout
+    huge = datagen.dither_set(700, 700, 0.3, 0.2, 5.0, 1.0, np.float32)
+    refs2 = refs[:2] + [bad] + refs[3:] + [huge[0]]
+    blts2 = blts + [huge[1:]]
+    fit, iccs, _ = find_linear_fit(refs2, blts2, fitgeom='shift', cc_type='NCC')
+    st = fit['subpixal_status']
+    assert st[2] == 6 and st[-1] == ST_SKIPPED and np.all(np.delete(st, [2, 10]) == 0)
+    assert not fit['fitmask'][2] and not fit['fitmask'][-1] and fit['fitmask'].sum() == 9
+    assert iccs[-1] is None and iccs[0].shape == (96, 96)
+    d = fit['subpixal_img_dxy']
+    np.testing.assert_allclose(np.delete(d, [2, 10], axis=0), np.delete(good_fit['subpixal_img_dxy'], 2, axis=0),
+                               atol=1e-12)
+    assert np.isfinite(fit['irmse']) and np.all(np.isfinite(fit['offset']))
+    # the fit equals the one over the nine good sources alone
+    keep = [k for k in range(10) if k != 2]
+    ref_fit, _, _ = find_linear_fit([refs[k] for k in keep], [blts[k] for k in keep], fitgeom='shift',
+                                    cc_type='NCC')
+    np.testing.assert_allclose(fit['offset'], ref_fit['offset'], atol=1e-9)
