@@ -162,6 +162,38 @@ template <int XS> SPX_DEVICE void transpose_tile(cf (&v)[8][8], float* xch, int 
     }
 }
 
+// The same transposition with whole complex elements (8 bytes) in two half-tile passes: pass h
+// moves the registers R in [32 h, 32 h + 32) as 32 rows of 66 complex slots (ds_write_b64 by all
+// lanes, conflict-free), and the lanes R of that range read their row back with 32 ds_read_b128.
+// No register shuffling on either side (-368 VALU instructions, -19 VGPRs) but the reads run on
+// half a wave: measured neutral to slightly slower on the 64 / 32 tiles, so it is used where the
+// registers matter more than the LDS issue slots (period-192 and general paths, 32-tile reference
+// mode: their spills go away).
+template <int XS> SPX_DEVICE void transpose_tile_cplx(cf (&v)[8][8], float* xch, int lane) {
+    constexpr int RS = 66;                                   // row stride in complex slots
+    static_assert(32 * RS * 2 <= 64 * XS, "half a tile must fit the wave's exchange buffer");
+    cf* buf = reinterpret_cast<cf*>(xch);
+    cf t[64];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) buf[r * RS + lane] = v[(32 * h + r) >> 3][(32 * h + r) & 7];
+        rt::wave_sync();
+        if ((lane >> 5) == h) {
+            const f32x4* row = reinterpret_cast<const f32x4*>(buf + (lane & 31) * RS);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const f32x4 q = row[j];
+                t[2 * j] = cf{q[0], q[1]};
+                t[2 * j + 1] = cf{q[2], q[3]};
+            }
+        }
+        rt::wave_sync();
+    }
+#pragma unroll
+    for (int r = 0; r < 64; ++r) v[r >> 3][r & 7] = t[r];
+}
+
 // ---------------------------------------------------------------------------
 // LDS map (bytes).  Everything is carved from one dynamic region.
 // ---------------------------------------------------------------------------

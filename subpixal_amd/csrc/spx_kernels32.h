@@ -99,7 +99,8 @@ SPX_DEVICE NormStatsT<TIn> norm_stats_wave(const TIn* __restrict__ ref, const TI
 
 // (ref, flipped img) of one pair -> the four real class planes in the wave's buffer `wbuf`.
 // Returns the exact power-of-two balance factor applied to the image.
-template <typename TIn>
+// CPLX: the register-saving transposition (transpose_tile_cplx), used by the reference-mode kernel
+template <typename TIn, bool CPLX = false>
 SPX_DEVICE float cc_planes32(const cf* tw, float* wbuf, const TIn* __restrict__ ref,
                              const TIn* __restrict__ img, int ny, int nx, const NormStatsT<TIn>& ns) {
     typedef Lds32 L;
@@ -172,7 +173,7 @@ SPX_DEVICE float cc_planes32(const cf* tw, float* wbuf, const TIn* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j][kb] = cmul(v[j][kb], wx);
     }
-    transpose_tile<L::XS>(v, wbuf, lane);
+    if constexpr (CPLX) transpose_tile_cplx<L::XS>(v, wbuf, lane); else transpose_tile<L::XS>(v, wbuf, lane);
     // ---- forward round B (radix-4 per class), W = Z^2, inverse round A'
     fft4_classes<1>(v);
 #pragma unroll
@@ -192,7 +193,7 @@ SPX_DEVICE float cc_planes32(const cf* tw, float* wbuf, const TIn* __restrict__ 
                 SPX_E32(c, y0, x0) = e;
             }
         }
-    transpose_tile<L::XS>(v, wbuf, lane);
+    if constexpr (CPLX) transpose_tile_cplx<L::XS>(v, wbuf, lane); else transpose_tile<L::XS>(v, wbuf, lane);
     // ---- inverse round B'
     fft8_y<-1>(v);
     fft8_x<-1>(v);
@@ -496,7 +497,7 @@ SPX_TKERNEL(256) void disp5_32_kernel(const TIn* __restrict__ ref, const TIn* __
         int bi = 0x7fffffff;
         for (int q = 0; q < 4; ++q) {
             const int ox = q & 1, oy = q >> 1;
-            const float bal = cc_planes32(tw, wbuf, r, m4 + q * stride, ny, nx, ns);
+            const float bal = cc_planes32<TIn, true>(tw, wbuf, r, m4 + q * stride, ny, nx, ns);
             const float oscale = 1.0f / ((float)(L::P * L::P) * bal);
             for (int idx = lane; idx < ny * nx; idx += 64) {
                 const int qy = idx / nx, qx = idx - qy * nx;

@@ -174,7 +174,7 @@ SPX_DEVICE void class_round_big(unsigned char* lds, const BigGeom& G, const TIn*
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j][kb] = cmul(v[j][kb], wx);
     }
-    transpose_tile<L::XS>(v, xch, lane);
+    transpose_tile_cplx<L::XS>(v, xch, lane);
     fft8_y<1>(v);
     fft8_x<1>(v);
 #pragma unroll
@@ -193,7 +193,7 @@ SPX_DEVICE void class_round_big(unsigned char* lds, const BigGeom& G, const TIn*
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j][x0] = cmulc(v[j][x0], wx);
     }
-    transpose_tile<L::XS>(v, xch, lane);
+    transpose_tile_cplx<L::XS>(v, xch, lane);
     fft8_y<-1>(v);
     fft8_x<-1>(v);
     // class post-twiddle conj(w_P^{8 (cy y1 + cx x1)})
