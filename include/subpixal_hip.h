@@ -74,6 +74,7 @@ extern "C" {
 #define SPX_ST_OUTSIDE 3   /* vertex outside image -> integer peak  (centroid.py:230)    */
 #define SPX_ST_WINDOW 4    /* fine peak not bracketed by the refinement window           */
 #define SPX_ST_FEWPTS 5    /* find_peak: fewer than 6 usable points (centroid.py:160,186,202) */
+#define SPX_ST_SHAPE 7     /* variable-shape batch: item outside the launched kernel family's sizes */
 #define SPX_ST_NONFINITE 6 /* a NaN/Inf pixel made the correlation NaN: integer position (0, 0),
                               which is what numpy.argmax + centroid.py:171 return for it        */
 
@@ -156,6 +157,32 @@ int spx_find_displacement5_f64(const double* ref, const double* im4, int64_t nba
                                int nx, int cc_type, double* out_dxdy, int32_t* out_status,
                                float* out_icc, void* workspace, size_t workspace_bytes,
                                void* stream);
+
+/*
+ * Reference mode over cutouts of DIFFERENT shapes in one launch (the reference's cutouts are
+ * bounding boxes + padding, one shape per source: cutout.py:159-175, 1023-1031; the loop at
+ * align.py:656-699 handles them one by one).  Items are packed back to back:
+ *   item_offset : int64 [nbatch]     element offset of item k's reference cutout in `ref`; its four
+ *                                    dithers start at 4*item_offset[k] of `im4` (image00, 10, 01, 11,
+ *                                    ny*nx apart), its interlaced image at 4*item_offset[k] of `out_icc`
+ *   item_shape  : int32 [nbatch][2]  (ny, nx) of item k
+ *   family_side : any side length of the kernel family every item belongs to: items up to 32 px
+ *                 with items up to 32 px, up to 64 with up to 64, up to 85 with up to 85, up to 128
+ *                 with up to 128 (a family also takes every smaller shape; the Python layer groups
+ *                 by the smallest one).  An item outside [3, family maximum] is not computed:
+ *                 (NaN, NaN), status SPX_ST_SHAPE.
+ *   out_icc     : required (float32, 4 * total pixels); workspace: spx_workspace_bytes_xcorr(nbatch,
+ *                 family_side, family_side) bytes.
+ * Cutouts above 128 px (general path: tables depend on the size) go through the uniform entry.
+ */
+int spx_find_displacement5_var_f32(const float* ref, const float* im4, const int64_t* item_offset,
+                                   const int32_t* item_shape, int64_t nbatch, int family_side,
+                                   int cc_type, double* out_dxdy, int32_t* out_status, float* out_icc,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+int spx_find_displacement5_var_f64(const double* ref, const double* im4, const int64_t* item_offset,
+                                   const int32_t* item_shape, int64_t nbatch, int family_side,
+                                   int cc_type, double* out_dxdy, int32_t* out_status, float* out_icc,
+                                   void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * General find_peak (centroid.py:18-236), one image per workgroup.

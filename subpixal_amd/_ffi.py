@@ -15,7 +15,7 @@ MAX_UPSAMPLE = 59
 
 CC_CODES = {'CC': 0, 'NCC': 1, 'ZNCC': 2}
 
-ST_OK, ST_EDGE, ST_NOMAX, ST_OUTSIDE, ST_WINDOW, ST_FEWPTS, ST_NONFINITE = range(7)
+ST_OK, ST_EDGE, ST_NOMAX, ST_OUTSIDE, ST_WINDOW, ST_FEWPTS, ST_NONFINITE, ST_SHAPE = range(8)
 
 _c = ctypes
 _vp = _c.c_void_p
@@ -37,6 +37,10 @@ _SIGNATURES = {
                                               _c.c_int, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     'spx_find_displacement5_f64': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int,
                                               _c.c_int, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
+    'spx_find_displacement5_var_f32': (_c.c_int, [_vp, _vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _vp, _vp,
+                                                  _vp, _vp, _c.c_size_t, _vp]),
+    'spx_find_displacement5_var_f64': (_c.c_int, [_vp, _vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _vp, _vp,
+                                                  _vp, _vp, _c.c_size_t, _vp]),
     'spx_find_peak_f64': (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                      _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _vp]),
     'spx_gather_cutouts_f32': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _vp, _c.c_int64,

@@ -130,35 +130,18 @@ def iter_linear_fit(xy, uv, wxy=None, wuv=None, fitgeom='general', center=None, 
 # ----------------------------------------------------------------------------
 def measure_shifts(ref_tiles, im4_tiles, cc_type='NCC', full_output=False, return_status=False):
     """Displacements for lists of same-or-mixed-shape cutouts: ``ref_tiles[k]`` is a 2-D
-    array, ``im4_tiles[k]`` its four dithered blots (00, 10, 01, 11).  One launch per
-    distinct shape.  Returns ``dxdy [N, 2]`` (then the list of interlaced images with
+    array, ``im4_tiles[k]`` its four dithered blots (00, 10, 01, 11).  One launch per kernel
+    family (``cc.find_displacement_var``), not per shape.  Returns ``dxdy [N, 2]`` (then the list of interlaced images with
     ``full_output``, then ``status [N]`` with ``return_status``).  A cutout whose shape the kernels
     do not take (outside 3..128 px per side) is not measured: shift 0, status ST_SKIPPED --
     one oversized source must not abort the whole fit."""
-    n = len(ref_tiles)
-    dxdy = np.zeros((n, 2), dtype=np.float64)
-    status = np.full(n, ST_SKIPPED, dtype=np.int32)
-    iccs = [None] * n
-    groups = {}
     for k, r in enumerate(ref_tiles):
         shapes = {np.shape(r)} | {np.shape(b) for b in im4_tiles[k]}
         if len(shapes) != 1:
             raise ValueError("All cutouts must have same shape.")       # cc.py:103-105
-        if _shape_ok(np.shape(r)):
-            groups.setdefault(np.shape(r), []).append(k)
-    for shape, idx in groups.items():
-        f64 = all(np.asarray(ref_tiles[k]).dtype == np.float64 for k in idx)
-        dt = np.float64 if f64 else np.float32
-        ref = np.stack([np.asarray(ref_tiles[k], dtype=dt) for k in idx])
-        im4 = np.stack([np.stack([np.asarray(b, dtype=dt) for b in im4_tiles[k]])
-                        for k in idx])
-        res = cc.find_displacement_batch(ref, im4, cc_type=cc_type, full_output=full_output,
-                                         return_status=True)
-        dxdy[idx] = res[0]
-        status[idx] = res[-1]
-        if full_output:
-            for j, k in enumerate(idx):
-                iccs[k] = res[1][j]
+    dxdy, iccs, status = cc.find_displacement_var(ref_tiles, im4_tiles, cc_type=cc_type, full_output=True,
+                                                  return_status=True)
+    dxdy = np.where(status[:, None] == ST_SKIPPED, 0.0, dxdy)          # not measured: shift 0, zero weight
     out = [dxdy]
     if full_output:
         out.append(iccs)

@@ -11,7 +11,7 @@ import torch
 
 from . import _ffi, device
 
-__all__ = ['find_displacement', 'find_displacement_batch', 'xcorr_refine_batch']
+__all__ = ['find_displacement', 'find_displacement_batch', 'find_displacement_var', 'xcorr_refine_batch']
 
 
 def _cc_code(cc_type):
@@ -104,6 +104,90 @@ def find_displacement_batch(ref, im4, cc_type='NCC', full_output=False, return_s
         res.append(_finish(icc, like_torch))
     if return_status:
         res.append(_finish(status, like_torch))
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+_FAMILIES = (32, 64, 85, 128)        # largest side of the kernel families that take mixed shapes
+
+
+def find_displacement_var(refs, im4s, cc_type='NCC', full_output=False, return_status=False):
+    """``find_displacement`` for cutouts of DIFFERENT shapes: ``refs[k]`` is a 2-D array, ``im4s[k]`` its
+    four dithered blots (a ``[4, ny, nx]`` array or a 4-sequence, order 00, 10, 01, 11).  The reference's
+    cutouts are bounding boxes + padding, one shape per source (cutout.py:159-175), and its loop
+    (align.py:656-699) takes them one at a time; here all sources of one kernel family (sides up to 32 /
+    64 / 85 / 128 px) go in ONE launch (``spx_find_displacement5_var_*``), larger ones in one launch per shape.
+
+    Returns ``dxdy [N, 2]`` float64 (numpy), then the list of interlaced images with ``full_output``, then
+    ``status [N]`` with ``return_status``; a cutout the kernels do not take (side below 3 or above 682) is
+    not measured: (nan, nan), status -1."""
+    n = len(refs)
+    dxdy = np.full((n, 2), np.nan)
+    status = np.full(n, -1, dtype=np.int32)
+    iccs = [None] * n
+    groups, big = {}, {}
+    for k in range(n):
+        r = np.asarray(refs[k])
+        b = [np.asarray(x) for x in im4s[k]]
+        if r.ndim != 2 or len(b) != 4 or any(x.shape != r.shape for x in b):
+            raise ValueError("All cutouts must have same shape.")           # cc.py:103-105
+        side = max(r.shape)
+        if min(r.shape) < 3 or side > _ffi.MAX_SIDE:
+            continue
+        dt = np.float64 if r.dtype == np.float64 and all(x.dtype == np.float64 for x in b) else np.float32
+        if side > _FAMILIES[-1]:
+            big.setdefault((r.shape, dt), []).append(k)
+        else:
+            fam = next(f for f in _FAMILIES if side <= f)
+            groups.setdefault((fam, dt), []).append(k)
+    lib = _ffi.load()
+    dev = device.init()
+    for (fam, dt), idx in groups.items():
+        shapes = np.array([np.shape(refs[k]) for k in idx], dtype=np.int32)
+        sizes = shapes[:, 0].astype(np.int64) * shapes[:, 1]
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        total = int(sizes.sum())
+        ref_flat = np.empty(total, dtype=dt)
+        im4_flat = np.empty(4 * total, dtype=dt)
+        for j, k in enumerate(idx):
+            o, sz = int(offs[j]), int(sizes[j])
+            ref_flat[o:o + sz] = np.asarray(refs[k], dtype=dt).ravel()
+            for q in range(4):
+                im4_flat[4 * o + q * sz:4 * o + (q + 1) * sz] = np.asarray(im4s[k][q], dtype=dt).ravel()
+        tdt = torch.float64 if dt == np.float64 else torch.float32
+        r_d = device.to_device(ref_flat, tdt)
+        m_d = device.to_device(im4_flat, tdt)
+        o_d = device.to_device(offs, torch.int64)
+        s_d = device.to_device(shapes.ravel(), torch.int32)
+        out = torch.empty((len(idx), 2), dtype=torch.float64, device=r_d.device)
+        st = torch.empty((len(idx),), dtype=torch.int32, device=r_d.device)
+        icc = torch.empty((4 * total,), dtype=torch.float32, device=r_d.device)
+        fn = lib.spx_find_displacement5_var_f64 if dt == np.float64 else lib.spx_find_displacement5_var_f32
+        with torch.cuda.device(r_d.device):
+            ws, ws_bytes = _workspace(lib.spx_workspace_bytes_xcorr(len(idx), fam, fam), r_d.device)
+            _ffi.check(fn(device.ptr(r_d), device.ptr(m_d), device.ptr(o_d), device.ptr(s_d), len(idx), fam,
+                          _cc_code(cc_type), device.ptr(out), device.ptr(st), device.ptr(icc),
+                          device.ptr(ws), ws_bytes, device.stream_ptr()))
+        dxdy[idx] = out.cpu().numpy()
+        status[idx] = st.cpu().numpy()
+        if full_output:
+            icc_h = icc.cpu().numpy()
+            for j, k in enumerate(idx):
+                o, (ny, nx) = int(offs[j]), shapes[j]
+                iccs[k] = icc_h[4 * o:4 * o + 4 * ny * nx].reshape(2 * ny, 2 * nx)
+    for (shape, dt), idx in big.items():            # general path: one launch per shape
+        ref = np.stack([np.asarray(refs[k], dtype=dt) for k in idx])
+        im4 = np.stack([np.stack([np.asarray(x, dtype=dt) for x in im4s[k]]) for k in idx])
+        d, icc, st = find_displacement_batch(ref, im4, cc_type=cc_type, full_output=True, return_status=True)
+        dxdy[idx] = d
+        status[idx] = st
+        if full_output:
+            for j, k in enumerate(idx):
+                iccs[k] = icc[j]
+    res = [dxdy]
+    if full_output:
+        res.append(iccs)
+    if return_status:
+        res.append(status)
     return res[0] if len(res) == 1 else tuple(res)
 
 

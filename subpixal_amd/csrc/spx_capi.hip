@@ -275,6 +275,7 @@ struct Disp5Args {
     int32_t* status;
     float* ws;
     hipStream_t s;
+    spx::ItemTable items;        // per-item offsets and shapes, or nulls for a uniform batch
 };
 template <typename TIn>
 int run_disp5(DeviceTables* t, Tile tile, bool fold, const TIn* ref, const TIn* im4,
@@ -286,7 +287,7 @@ int run_disp5(DeviceTables* t, Tile tile, bool fold, const TIn* ref, const TIn* 
         if (rc || !launch) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid_big(t->num_cu, a.nbatch)), dim3(spx::kThreads), lds,
                            a.s, ref, im4, a.nbatch, a.ny, a.nx, a.cc_type, t->tw[TILE192], a.icc, a.out,
-                           a.status, a.ws);
+                           a.status, a.ws, a.items);
         SPX_HIP(hipGetLastError());
         return 0;
     }
@@ -296,7 +297,7 @@ int run_disp5(DeviceTables* t, Tile tile, bool fold, const TIn* ref, const TIn* 
         int rc = allow_lds(t, kern, lds);
         if (rc || !launch) return rc;
         hipLaunchKernelGGL(kern, dim3(grid_for(t, (a.nbatch + 3) / 4)), dim3(spx::kThreads), lds, a.s, ref,
-                           im4, a.nbatch, a.ny, a.nx, a.cc_type, t->tw[TILE32], a.icc, a.out, a.status);
+                           im4, a.nbatch, a.ny, a.nx, a.cc_type, t->tw[TILE32], a.icc, a.out, a.status, a.items);
         SPX_HIP(hipGetLastError());
         return 0;
     }
@@ -305,7 +306,7 @@ int run_disp5(DeviceTables* t, Tile tile, bool fold, const TIn* ref, const TIn* 
     int rc = allow_lds(t, kern, lds);
     if (rc || !launch) return rc;
     hipLaunchKernelGGL(kern, dim3(grid_for(t, a.nbatch)), dim3(spx::kThreads), lds, a.s, ref, im4, a.nbatch,
-                       a.ny, a.nx, a.cc_type, t->tw[TILE64], a.icc, a.out, a.status);
+                       a.ny, a.nx, a.cc_type, t->tw[TILE64], a.icc, a.out, a.status, a.items);
     SPX_HIP(hipGetLastError());
     return 0;
 }
@@ -412,6 +413,7 @@ int find_displacement5(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, i
     int rc = current_tables(&t);
     if (rc) return rc;
     Disp5Args a;
+    a.items = spx::ItemTable{nullptr, nullptr, 0};
     a.nbatch = nbatch; a.ny = ny; a.nx = nx; a.cc_type = cc_type;
     a.icc = out_icc ? out_icc : reinterpret_cast<float*>(wsb + tile_ws);
     a.out = out_dxdy; a.status = out_status;
@@ -428,6 +430,38 @@ int find_displacement5(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, i
     }
     std::lock_guard<std::mutex> lk(t->launch_mu);
     return run_disp5<TIn>(t, tile_for(ny, nx), ny > 64 || nx > 64, ref, im4, a, true);
+}
+
+// reference mode over cutouts of different shapes, all within one kernel family (`family_side`)
+template <typename TIn>
+int find_displacement5_var(const TIn* ref, const TIn* im4, const int64_t* item_offset,
+                           const int32_t* item_shape, int64_t nbatch, int family_side, int cc_type,
+                           double* out_dxdy, int32_t* out_status, float* out_icc, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    if (nbatch < 0 || (nbatch > 0 && (!ref || !im4 || !item_offset || !item_shape || !out_dxdy || !out_icc)))
+        return fail(SPX_E_ARG, "null pointer or negative batch");
+    if (family_side < 3 || family_side > 128)
+        return fail(SPX_E_SHAPE, "variable-shape batches take cutouts of 3..128 pixels per side");
+    if (nbatch == 0) return 0;
+    const Tile tile = tile_for(family_side, family_side);
+    const size_t need = ws_bytes_xcorr(nbatch, family_side, family_side);
+    if (need > 0 && (!workspace || workspace_bytes < need))
+        return fail(SPX_E_WORKSPACE, "workspace missing or smaller than spx_workspace_bytes_xcorr()");
+    DeviceTables* t = nullptr;
+    int rc = current_tables(&t);
+    if (rc) return rc;
+    const bool fold = family_side > 64;
+    Disp5Args a;
+    // the largest side the family launched here takes: 32 / 64 / 85 (fold path) / 128
+    a.items = spx::ItemTable{item_offset, item_shape,
+                             tile == TILE32 ? 32 : (tile == TILE64 ? (fold ? kFoldMaxSide : 64) : 128)};
+    a.nbatch = nbatch; a.ny = family_side; a.nx = family_side; a.cc_type = cc_type;
+    a.icc = out_icc;
+    a.out = out_dxdy; a.status = out_status;
+    a.ws = reinterpret_cast<float*>(workspace);
+    a.s = reinterpret_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> lk(t->launch_mu);
+    return run_disp5<TIn>(t, tile, fold, ref, im4, a, true);
 }
 
 }  // namespace
@@ -609,6 +643,21 @@ int spx_find_displacement5_f64(const double* ref, const double* im4, int64_t nba
                                void* stream) {
     return find_displacement5<double>(ref, im4, nbatch, ny, nx, cc_type, out_dxdy, out_status, out_icc,
                                       workspace, workspace_bytes, stream);
+}
+
+int spx_find_displacement5_var_f32(const float* ref, const float* im4, const int64_t* item_offset,
+                                   const int32_t* item_shape, int64_t nbatch, int family_side,
+                                   int cc_type, double* out_dxdy, int32_t* out_status, float* out_icc,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    return find_displacement5_var<float>(ref, im4, item_offset, item_shape, nbatch, family_side, cc_type,
+                                         out_dxdy, out_status, out_icc, workspace, workspace_bytes, stream);
+}
+int spx_find_displacement5_var_f64(const double* ref, const double* im4, const int64_t* item_offset,
+                                   const int32_t* item_shape, int64_t nbatch, int family_side,
+                                   int cc_type, double* out_dxdy, int32_t* out_status, float* out_icc,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    return find_displacement5_var<double>(ref, im4, item_offset, item_shape, nbatch, family_side, cc_type,
+                                          out_dxdy, out_status, out_icc, workspace, workspace_bytes, stream);
 }
 
 int spx_find_peak_f64(const double* image, const uint8_t* mask, const double* guess,

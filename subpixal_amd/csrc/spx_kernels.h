@@ -52,7 +52,7 @@ constexpr int kThreads = 256;
 // hoisted out of the per-pair loop and kept -- i.e. spilled -- for the whole kernel.
 SPX_DEVICE int fresh_tid() { return rt::launder_lane(rt::thread_id()); }
 
-enum { ST_OK = 0, ST_EDGE = 1, ST_NOMAX = 2, ST_OUTSIDE = 3, ST_WINDOW = 4, ST_FEWPTS = 5, ST_NONFINITE = 6 };
+enum { ST_OK = 0, ST_EDGE = 1, ST_NOMAX = 2, ST_OUTSIDE = 3, ST_WINDOW = 4, ST_FEWPTS = 5, ST_NONFINITE = 6, ST_SHAPE = 7 };
 // index of an arg-max that saw no comparable value (NaN everywhere)
 constexpr int kNoIndex = 0x7fffffff;
 enum { CC_PLAIN = 0, CC_NCC = 1, CC_ZNCC = 2 };
@@ -1566,17 +1566,58 @@ SPX_DEVICE void disp5_body(const TIn* __restrict__ ref, const TIn* __restrict__ 
     }
 }
 
+// Batches of cutouts of DIFFERENT shapes (the reference's cutouts are bounding boxes + padding,
+// one shape per source: cutout.py:159-175, 1023-1031).  Item p's reference cutout starts at element
+// off[p] of `ref` (items packed back to back), its four dithers at 4 off[p] of `im4`, each
+// shp[2p] x shp[2p+1] = (ny, nx) pixels, its interlaced image at 4 off[p] of `icc`.  Null tables:
+// a uniform batch of (ny, nx) cutouts.  An item whose shape the kernel family launched for it cannot
+// take (side below 3 or above `max_side`) is not computed: (NaN, NaN), status ST_SHAPE.
+struct ItemTable {
+    const int64_t* off;
+    const int* shp;
+    int max_side;
+};
+struct ItemView {
+    int64_t off;
+    int ny, nx;
+    bool ok;
+};
+SPX_DEVICE ItemView item_view(const ItemTable& t, int64_t p, int ny, int nx) {
+    ItemView v;
+    if (t.off) {
+        v.off = t.off[p];
+        v.ny = t.shp[2 * p];
+        v.nx = t.shp[2 * p + 1];
+        v.ok = v.ny >= 3 && v.nx >= 3 && v.ny <= t.max_side && v.nx <= t.max_side;
+    } else {
+        v.off = p * ((int64_t)ny * nx);
+        v.ny = ny;
+        v.nx = nx;
+        v.ok = true;
+    }
+    return v;
+}
+SPX_DEVICE void item_refused(double* __restrict__ out, int* __restrict__ status, int64_t p, bool writer) {
+    if (writer) {
+        const double nan = __builtin_nan("");
+        out[2 * p] = nan;
+        out[2 * p + 1] = nan;
+        if (status) status[p] = ST_SHAPE;
+    }
+}
+
 template <int C, bool FOLD = false, typename TIn = float>
 SPX_TKERNEL(256) void disp5_kernel(const TIn* __restrict__ ref, const TIn* __restrict__ im4,
                                    int64_t nbatch, int ny, int nx, int cc_type,
                                    const cf* __restrict__ tw_g, float* __restrict__ icc,
-                                   double* __restrict__ out, int* __restrict__ status) {
+                                   double* __restrict__ out, int* __restrict__ status, ItemTable items) {
     SPX_DYN_LDS(lds);
     load_twiddles<C>(lds, tw_g);
-    const int64_t stride = (int64_t)ny * nx;
     for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
-        disp5_body<C, FOLD, TIn>(ref + p * stride, im4 + 4 * p * stride, ny, nx, cc_type, tw_g,
-                      icc + 4 * p * stride, out + 2 * p, status ? status + p : nullptr, lds);
+        const ItemView it = item_view(items, p, ny, nx);
+        if (!it.ok) { item_refused(out, status, p, rt::thread_id() == 0); continue; }
+        disp5_body<C, FOLD, TIn>(ref + it.off, im4 + 4 * it.off, it.ny, it.nx, cc_type, tw_g,
+                      icc + 4 * it.off, out + 2 * p, status ? status + p : nullptr, lds);
         rt::block_sync_lds();
     }
 }

@@ -630,18 +630,23 @@ SPX_TKERNEL(256) void disp5_128_kernel(const TIn* __restrict__ ref, const TIn* _
                                        int64_t nbatch, int ny, int nx, int cc_type,
                                        const cf* __restrict__ tw_g, float* __restrict__ icc_all,
                                        double* __restrict__ out_all, int* __restrict__ status,
-                                       float* __restrict__ workspace) {
+                                       float* __restrict__ workspace, ItemTable items) {
     typedef LdsBig<C> L;
     SPX_DYN_LDS(lds);
     load_twiddles128<C>(lds, tw_g);
     float* ws = workspace + (size_t)rt::block_id() * (L::kWsBytes / sizeof(float));
     unsigned char* scr = lds + L::SCR_OFF;
-    const int64_t stride = (int64_t)ny * nx;
-    const int NX = 2 * nx, NY = 2 * ny;
+    const int ny_u = ny, nx_u = nx;
     for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
-        const TIn* r = ref + p * stride;
-        const TIn* m4 = im4 + 4 * p * stride;
-        float* icc = icc_all + 4 * p * stride;
+        const ItemView it = item_view(items, p, ny_u, nx_u);       // per-item shape (see spx_kernels.h)
+        if (!it.ok) { item_refused(out_all, status, p, rt::thread_id() == 0); continue; }
+        ny = it.ny;
+        nx = it.nx;
+        const int64_t stride = (int64_t)ny * nx;
+        const int NX = 2 * nx, NY = 2 * ny;
+        const TIn* r = ref + it.off;
+        const TIn* m4 = im4 + 4 * it.off;
+        float* icc = icc_all + 4 * it.off;
         const int tid = fresh_tid();
         const NormStatsT<TIn> ns = norm_stats(scr, r, m4, 4, stride, ny, nx, cc_type);
         float bv = -__builtin_inff();

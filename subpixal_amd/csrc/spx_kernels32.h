@@ -471,7 +471,8 @@ template <typename TIn = float>
 SPX_TKERNEL(256) void disp5_32_kernel(const TIn* __restrict__ ref, const TIn* __restrict__ im4,
                                       int64_t nbatch, int ny, int nx, int cc_type,
                                       const cf* __restrict__ tw_g, float* __restrict__ icc_all,
-                                      double* __restrict__ out_all, int* __restrict__ status) {
+                                      double* __restrict__ out_all, int* __restrict__ status,
+                                      ItemTable items) {
     typedef Lds32 L;
     SPX_DYN_LDS(lds);
     load_twiddles32(lds, tw_g);
@@ -481,13 +482,18 @@ SPX_TKERNEL(256) void disp5_32_kernel(const TIn* __restrict__ ref, const TIn* __
     const cf* tw = reinterpret_cast<const cf*>(lds + L::TW_OFF);
     float* wbuf = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::wave_bytes(16));
     double* fit = reinterpret_cast<double*>(lds + L::SCR_OFF + wave * 256);
-    const int64_t stride = (int64_t)ny * nx;
-    const int NX = 2 * nx, NY = 2 * ny;
+    const int ny_u = ny, nx_u = nx;
     for (int64_t p = rt::block_id() * 4 + wave; p < nbatch; p += rt::grid_size() * 4) {
         const int lane = fresh_tid() & 63;
-        const TIn* r = ref + p * stride;
-        const TIn* m4 = im4 + 4 * p * stride;
-        float* icc = icc_all + 4 * p * stride;
+        const ItemView it = item_view(items, p, ny_u, nx_u);       // per-item shape (see spx_kernels.h)
+        if (!it.ok) { item_refused(out_all, status, p, lane == 0); continue; }
+        ny = it.ny;
+        nx = it.nx;
+        const int64_t stride = (int64_t)ny * nx;
+        const int NX = 2 * nx, NY = 2 * ny;
+        const TIn* r = ref + it.off;
+        const TIn* m4 = im4 + 4 * it.off;
+        float* icc = icc_all + 4 * it.off;
         NormStatsT<TIn> ns = norm_stats_wave(r, m4, 4, stride, ny * nx, cc_type);
         ns.im_mean = rt::read_lane(ns.im_mean, 0);          // wave-uniform values -> scalar registers
         ns.im_std = rt::read_lane(ns.im_std, 0);

@@ -159,11 +159,15 @@ extern "C" int emu_pair_f64(const double* ref, const double* img, int64_t nbatch
 #endif   // EMU_PART 1, 2
 
 #if EMU_PART == 3
+// off/shp: per-item offsets and shapes (variable-shape batch of the family of (ny, nx)), or nulls
 template <typename TIn>
 static int emu_disp5_t(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, int nx,
-                       int cc_type, float* icc, double* out, int* status) {
+                       int cc_type, float* icc, double* out, int* status,
+                       const int64_t* off = nullptr, const int* shp = nullptr) {
     if (ny < 3 || nx < 3) return -1;
     const int n = ny > nx ? ny : nx;
+    if (off && n > 128) return -1;
+    const ItemTable items = {off, shp, n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 85 ? 85 : 128))};
     if (n > 128) {
         const int C = big_class_count(ny, nx);
         if (C > kBigMaxC) return -1;
@@ -180,7 +184,7 @@ static int emu_disp5_t(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, i
         std::vector<float> tw = host::make_twiddles(64);
         const cf* twp = reinterpret_cast<const cf*>(tw.data());
         rt::launch((nbatch + 3) / 4, kThreads, [&] {
-            disp5_32_kernel<TIn>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status);
+            disp5_32_kernel<TIn>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, items);
         }, Lds32::total(16));
         return 0;
     }
@@ -189,11 +193,11 @@ static int emu_disp5_t(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, i
         const cf* twp = reinterpret_cast<const cf*>(tw.data());
         if (n > 64)
             rt::launch(nbatch, kThreads,
-                       [&] { disp5_kernel<2, true, TIn>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status); },
+                       [&] { disp5_kernel<2, true, TIn>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, items); },
                        Lds<2>::total(0));
         else
             rt::launch(nbatch, kThreads,
-                       [&] { disp5_kernel<2, false, TIn>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status); },
+                       [&] { disp5_kernel<2, false, TIn>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, items); },
                        Lds<2>::total(0));
         return 0;
     }
@@ -202,7 +206,7 @@ static int emu_disp5_t(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, i
     std::vector<float> ws((size_t)nbatch * (kWs96Bytes / sizeof(float)));
     float* wsp = ws.data();
     rt::launch(nbatch, kThreads, [&] {
-        disp5_128_kernel<3, TIn>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, wsp);
+        disp5_128_kernel<3, TIn>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, wsp, items);
     }, LdsBig<3>::total(0));
     return 0;
 }
@@ -213,6 +217,11 @@ extern "C" int emu_disp5_f32(const float* ref, const float* im4, int64_t nbatch,
 extern "C" int emu_disp5_f64(const double* ref, const double* im4, int64_t nbatch, int ny, int nx,
                              int cc_type, float* icc, double* out, int* status) {
     return emu_disp5_t<double>(ref, im4, nbatch, ny, nx, cc_type, icc, out, status);
+}
+extern "C" int emu_disp5_var_f32(const float* ref, const float* im4, const int64_t* off, const int* shp,
+                                 int64_t nbatch, int family_side, int cc_type, float* icc, double* out,
+                                 int* status) {
+    return emu_disp5_t<float>(ref, im4, nbatch, family_side, family_side, cc_type, icc, out, status, off, shp);
 }
 
 #endif   // EMU_PART 3

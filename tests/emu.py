@@ -74,6 +74,28 @@ def disp5(ref, im4, cc=1):
     return out, st, icc
 
 
+def disp5_var(refs, im4s, family, cc=1):
+    """variable-shape batch (float32): lists of 2-D refs and [4, ny, nx] dither stacks"""
+    shapes = np.array([r.shape for r in refs], np.int32)
+    sizes = shapes[:, 0].astype(np.int64) * shapes[:, 1]
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    total = int(sizes.sum())
+    ref = np.concatenate([np.asarray(r, np.float32).ravel() for r in refs])
+    im4 = np.concatenate([np.asarray(m, np.float32).ravel() for m in im4s])
+    n = len(refs)
+    out = np.zeros((n, 2))
+    st = np.zeros(n, np.int32)
+    icc = np.zeros(4 * total, np.float32)
+    i64 = ctypes.POINTER(ctypes.c_int64)
+    rc = lib().emu_disp5_var_f32(_p(ref, _fp), _p(im4, _fp), offs.ctypes.data_as(i64),
+                                 shapes.ctypes.data_as(_ip), ctypes.c_int64(n), int(family), int(cc),
+                                 _p(icc, _fp), _p(out, _dp), _p(st, _ip))
+    assert rc == 0, rc
+    iccs = [icc[4 * int(o):4 * int(o) + 4 * int(s)].reshape(2 * sh[0], 2 * sh[1])
+            for o, s, sh in zip(offs, sizes, shapes)]
+    return out, st, iccs
+
+
 def find_peak(images, guesses=None, fit=(5, 5), search=(0, 0), masks=None):
     images = np.ascontiguousarray(images, np.float64)
     n, ny, nx = images.shape

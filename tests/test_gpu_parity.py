@@ -362,6 +362,42 @@ def test_find_displacement_goldens(spx, golden_dir):
     print('worst 5-image |d| vs reference: %.3g px' % worst)
 
 
+def test_find_displacement_variable_shapes(spx):
+    """One launch per kernel family for sources of different shapes (cutout shapes are
+    variable per source; the reference loops over them, align.py:656-699): same displacements, interlaced
+    images and status as cutout-by-cutout `find_displacement`, float32 and float64, including a cutout on
+    the general path (> 128 px), one with a NaN pixel and one too small to be measured."""
+    rng = np.random.default_rng(12)
+    shapes = [(20, 31), (5, 9), (64, 40), (33, 50), (64, 64), (70, 80), (85, 85), (40, 66), (100, 90),
+              (128, 128), (86, 30), (150, 131), (2, 50), (48, 48)]
+    for dt in (np.float32, np.float64):
+        refs, ims = [], []
+        for (ny, nx) in shapes:
+            t = datagen.dither_set(ny, nx, rng.uniform(-1, 1), rng.uniform(-1, 1), max(1.0, min(ny, nx) / 10),
+                                   rng.uniform(0.5, 2), dt, noise_seed=int(rng.integers(1, 1 << 30)), noise_level=0.01)
+            refs.append(t[0])
+            ims.append(np.stack(t[1:]))
+        refs[-1] = refs[-1].copy()
+        refs[-1][4, 4] = np.nan
+        for name in ('NCC', 'ZNCC'):
+            d, iccs, st = spx.find_displacement_var(refs, ims, cc_type=name, full_output=True, return_status=True)
+            assert d.shape == (len(shapes), 2) and len(iccs) == len(shapes)
+            for k, (ny, nx) in enumerate(shapes):
+                if min(ny, nx) < 3:
+                    assert st[k] == -1 and np.all(np.isnan(d[k])) and iccs[k] is None
+                    continue
+                s2 = []
+                e = orc.find_displacement(refs[k], *ims[k], cc_type=name, _status=s2)
+                assert st[k] == s2[-1], (k, st[k], s2)
+                assert np.max(np.abs(d[k] - np.array(e))) < 3e-5, (dt, name, ny, nx)
+                assert iccs[k].shape == (2 * ny, 2 * nx)
+                one, icc1 = spx.find_displacement_batch(refs[k][None], ims[k][None], cc_type=name, full_output=True)
+                # (the uniform call may pick a smaller kernel family for this shape: same numbers up to
+                #  float32 rounding, bit-identical when the family is the same)
+                assert np.max(np.abs(one[0] - d[k])) < 2e-6 or st[k] == 6
+            assert st[-1] == 6
+
+
 def test_find_displacement_single_call_api(spx, golden_dir):
     g = _load(golden_dir, 'find_displacement.npz')
     for tag in 'ab':

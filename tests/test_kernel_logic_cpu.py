@@ -381,3 +381,30 @@ def test_peak_beyond_the_last_coarse_sample_is_bracketed():
             assert st[0] == s2[-1] == 0, (n, st, s2)
             assert np.max(np.abs(got[0] - np.array(e))) < 1e-4, (n, got, e)
             assert max(got[0]) > n // 2 + 0.7
+
+
+def test_variable_shape_batches():
+    """Cutouts of different shapes in one launch per kernel family (the reference's cutouts are bounding
+    boxes + padding, one shape per source: cutout.py:159-175): same numbers as cutout-by-cutout calls;
+    an item the launched family cannot take is refused with SPX_ST_SHAPE, not computed wrongly."""
+    rng = np.random.default_rng(2)
+    for fam, shapes in ((32, [(20, 31), (5, 9), (3, 40)]), (64, [(64, 40), (33, 50), (20, 20)]),
+                        (85, [(70, 80), (40, 66), (90, 20)]), (128, [(100, 90), (86, 30), (50, 50)])):
+        refs, ims = [], []
+        for (ny, nx) in shapes:
+            t = datagen.dither_set(ny, nx, rng.uniform(-1, 1), rng.uniform(-1, 1), max(1.0, min(ny, nx) / 10), 1.0,
+                                   np.float32, noise_seed=5, noise_level=0.01)
+            refs.append(t[0])
+            ims.append(np.stack(t[1:]))
+        out, st, iccs = emu.disp5_var(refs, ims, fam, 1)
+        for k, (ny, nx) in enumerate(shapes):
+            if max(ny, nx) > fam:
+                assert st[k] == 7 and np.all(np.isnan(out[k]))
+                continue
+            s2 = []
+            e = orc.find_displacement(refs[k], *ims[k], cc_type='NCC', _status=s2)
+            assert np.abs(out[k] - np.array(e)).max() < 2e-5 and st[k] == s2[-1], (fam, ny, nx)
+            one, st1, icc1 = emu.disp5(refs[k][None], ims[k][None], 1)
+            if max(ny, nx) > (0 if fam == 32 else 32 if fam == 64 else 64 if fam == 85 else 85):
+                # same kernel family as the uniform call would pick: bit-identical
+                assert np.array_equal(one[0], out[k]) and np.array_equal(icc1[0], iccs[k])
