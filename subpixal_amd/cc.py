@@ -146,13 +146,9 @@ def find_displacement_var(refs, im4s, cc_type='NCC', full_output=False, return_s
         sizes = shapes[:, 0].astype(np.int64) * shapes[:, 1]
         offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
         total = int(sizes.sum())
-        ref_flat = np.empty(total, dtype=dt)
-        im4_flat = np.empty(4 * total, dtype=dt)
-        for j, k in enumerate(idx):
-            o, sz = int(offs[j]), int(sizes[j])
-            ref_flat[o:o + sz] = np.asarray(refs[k], dtype=dt).ravel()
-            for q in range(4):
-                im4_flat[4 * o + q * sz:4 * o + (q + 1) * sz] = np.asarray(im4s[k][q], dtype=dt).ravel()
+        # packed back to back: [item][pixels] and [item][dither][pixels]
+        ref_flat = np.concatenate([np.asarray(refs[k], dtype=dt).ravel() for k in idx])
+        im4_flat = np.concatenate([np.asarray(x, dtype=dt).ravel() for k in idx for x in im4s[k]])
         tdt = torch.float64 if dt == np.float64 else torch.float32
         r_d = device.to_device(ref_flat, tdt)
         m_d = device.to_device(im4_flat, tdt)
