@@ -46,9 +46,10 @@
  *     (a per-device mutex held only while a launch is issued).
  *   - Dynamic range: the transforms are float32.  The two cutouts of a pair may differ in amplitude
  *     by any factor up to 2^+-100 (they are balanced by an exact power of two before the product), but
- *     each must satisfy sum(pixel^2) < 3.4e38, i.e. amplitude * sqrt(npix) < 1.8e19 in plain CC mode
- *     (NCC/ZNCC normalise first); beyond that the correlation overflows and the item comes back as
- *     SPX_ST_NONFINITE rather than as a wrong shift.
+ *     in plain CC mode each must keep sum(|pixel|) below ~6e18 (the zero-frequency term of the packed
+ *     spectrum, sum(ref) + i sum(img), is squared in float32; NCC/ZNCC normalise first); beyond that
+ *     the correlation overflows and the item comes back as SPX_ST_NONFINITE rather than as a wrong
+ *     shift.
  *   - Input element types: the _f32 entries take float32 pixels (the type BASELINE.json
  *     measures); the _f64 entries take float64 pixels and form the `!= 0` masks, the pooled
  *     statistics and the normalised pixels of cc.py:131-156 in float64 -- the dtype the

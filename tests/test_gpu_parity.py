@@ -302,6 +302,21 @@ def test_peak_beyond_the_last_coarse_sample(spx):
                 assert np.max(np.abs(got[k] - np.array(e))) < 3e-4, (n, up, got[k], e)
 
 
+def test_dynamic_range_of_plain_cc(spx):
+    """ref*1e15 against img*1e-15 used to come back 12 px off with status 0 -- the
+    balance factor was skipped when the amplitude ratio left [1e-30, 1e30].  It is now taken from the
+    exponent fields (any ratio up to 2^+-100); an input whose sum of squares overflows float32 is flagged."""
+    ref, img, truth = datagen.pair_batch(17, 8, 64)
+    base = spx.xcorr_refine_batch(ref, img, upsample=10)
+    for a, b in ((1e15, 1e-15), (1e-15, 1e15), (1e16, 1e-18), (1e-12, 1e-12)):
+        got, st = spx.xcorr_refine_batch(ref * np.float32(a), img * np.float32(b), upsample=10, return_status=True)
+        assert int(np.abs(st).max()) == 0, (a, b, st)
+        assert np.max(np.abs(got - base)) < 2e-4, (a, b, np.max(np.abs(got - base)))
+        assert np.max(np.abs(got - truth)) < 1e-3
+    got, st = spx.xcorr_refine_batch(ref * np.float32(1e25), img, upsample=10, return_status=True)
+    assert np.all(st == 6)                      # the squared spectrum overflows float32: flagged, not wrong
+
+
 def test_shape_and_upsample_limits(spx):
     from subpixal_amd._ffi import SubpixalHipError
     a = np.zeros((2, 683, 64), np.float32)
