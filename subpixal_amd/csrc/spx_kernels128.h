@@ -446,7 +446,7 @@ SPX_DEVICE void fine_window128(unsigned char* lds, const double* __restrict__ kt
 #pragma unroll
         for (int t = 0; t < TPW; ++t) acc[ab][t] = f64x4{0., 0., 0., 0.};
     const int col0 = L::wrap(lxc + CW * wave + TPW * lj - L::P / 2);     // + t (wrap copy in the row)
-#pragma unroll 2
+#pragma unroll 4
     for (int s4 = 0; s4 < NQ; ++s4) {
         double kb[WB][4];
 #pragma unroll

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Wider randomized parity sweep than tests/test_gpu_parity.py::test_randomized_shapes_sweep:
-all three tiles, every refinement-window size (upsample up to 59), the three cc types, noisy
+all five kernel families, every refinement-window size (upsample up to 59), the three cc types, noisy
 cutouts; GPU against the oracle.  Prints the worst error per (tile, window blocks) bucket.
 
     python tools/sweep_parity.py [--trials 300] [--seed 1] [--budget 420]
@@ -31,8 +31,9 @@ done = 0
 for trial in range(a.trials):
     if time.time() - t0 > a.budget:
         break
-    tile = int(rng.choice([32, 64, 128], p=[0.3, 0.5, 0.2]))
-    lo = {32: 5, 64: 33, 128: 65}[tile]
+    # kernel families: 32 tile, 64 tile, its fold path (65..85), period 192 (86..128), general path
+    tile = int(rng.choice([32, 64, 85, 128, 200], p=[0.2, 0.3, 0.2, 0.2, 0.1]))
+    lo = {32: 5, 64: 33, 85: 65, 128: 86, 200: 129}[tile]
     ny, nx = int(rng.integers(lo, tile + 1)), int(rng.integers(5, tile + 1))
     if rng.random() < 0.5:
         ny, nx = nx, ny
@@ -56,9 +57,9 @@ for trial in range(a.trials):
     key = (tile, (up + 5 + 15) // 16 if up > 1 else 0)
     worst[key] = max(worst.get(key, 0.0), err)
     done += 1
-    # float32 accumulation of the fine window limits the 5x5 fit on very fine grids: cutouts above
-    # 64 px at upsample >= 20 with noisy data reach 3e-3 px (statuses identical); everything else < 1e-3
-    limit = 4e-3 if (tile == 128 and up >= 20) else 1e-3
+    # north_star: 1e-3 px.  (Round 1 needed 4e-3 on the 128 tile at upsample >= 20: float32 accumulation
+    # of the fine window; above 85 px it accumulates in float64 now.)
+    limit = 1e-3
     if not np.array_equal(st, est) or err > limit:
         bad += 1
         print('MISMATCH', ny, nx, up, name, err, st, est, flush=True)
