@@ -28,12 +28,16 @@ def init(device=None):
     return device
 
 
-def prepare(upsample=1):
+def prepare(upsample=1, shape=None):
     """Build the constant tables of ``upsample`` for every kernel family on the current device and
     raise the kernels' LDS limits (``spx_prepare``): afterwards launches neither allocate nor set
-    function attributes, so they can be captured into a HIP graph."""
+    function attributes, so they can be captured into a HIP graph.  Cutouts above 128 px (general
+    path) need tables that depend on their size: pass ``shape=(ny, nx)`` (``spx_prepare_shape``)."""
     init()
-    _ffi.check(_ffi.load().spx_prepare(int(upsample)))
+    if shape is None:
+        _ffi.check(_ffi.load().spx_prepare(int(upsample)))
+    else:
+        _ffi.check(_ffi.load().spx_prepare_shape(int(shape[0]), int(shape[1]), int(upsample)))
 
 
 def shutdown():

@@ -60,7 +60,7 @@ def test_graph_capture_reference_mode():
     assert torch.equal(out, eager)
 
 
-@pytest.mark.parametrize('n,up', [(32, 7), (80, 9), (96, 11), (128, 21)])
+@pytest.mark.parametrize('n,up', [(32, 7), (80, 9), (96, 11), (128, 21), (150, 13)])
 def test_capture_every_kernel_family_without_prior_eager_call(n, up):
     """spx_prepare(upsample) builds the tables of EVERY kernel family and raises
     every kernel's LDS limit, so the very first launch at a (shape, upsample) can already sit
@@ -70,8 +70,8 @@ def test_capture_every_kernel_family_without_prior_eager_call(n, up):
     import torch
     import datagen
     from subpixal_amd import cc, device
-    device.prepare(up)
-    ref, img, truth = _pairs(100 + n, count=512, n=n)
+    device.prepare(up, shape=(n, n) if n > 128 else None)      # general path: size-dependent tables
+    ref, img, truth = _pairs(100 + n, count=512 if n <= 128 else 64, n=n)
     r5, m4, _ = datagen.dither_batch(n, 8, n)
     r5 = torch.as_tensor(r5, device='cuda')
     m4 = torch.as_tensor(m4, device='cuda')
