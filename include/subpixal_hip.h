@@ -10,8 +10,12 @@
  *                                   im11, cc_type, full_output)   subpixal/cc.py:21-95,
  *                                   called once per source at subpixal/align.py:682-685;
  *                                   here for a whole batch (the loop align.py:656-699
- *                                   carries no state between sources).
- *   spx_xcorr_refine_f32        <-  the pair / upsample=U form of the same path that
+ *                                   carries no state between sources).  _f64: float64 cutouts.
+ *   spx_find_displacement5_var_f32 / _f64
+ *                               <-  the same loop over sources whose cutouts differ in shape
+ *                                   (bounding box + padding per source, cutout.py:159-175), one
+ *                                   launch per kernel family.
+ *   spx_xcorr_refine_f32 / _f64 <-  the pair / upsample=U form of the same path that
  *                                   BASELINE.json measures (one fftconvolve, cc.py:114,
  *                                   + find_peak, cc.py:86, on a U-times finer grid).
  *   spx_find_peak_f64           <-  centroid.find_peak(image, xmax, ymax, peak_fit_box,
