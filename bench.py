@@ -166,8 +166,8 @@ def kernel_build():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--pairs', type=int, default=None,
                     help='pairs per GPU (default 1e5 = configs[1]; at 8 GPUs 1.25e6 = configs[3], 1e7 pairs in all)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
