@@ -501,6 +501,22 @@ SPX_DEVICE ChunkLoad<TIn> chunk_issue(const TIn* __restrict__ ref, const TIn* __
     ChunkLoad<TIn> c;
     c.in = y < ny && x < nx;
     const int yy = y < ny ? y : ny - 1;
+    if (nx < 4) {
+        // rows shorter than a chunk (3-pixel-wide cutouts, reference mode only; wave-uniform branch):
+        // a 4-element load would reach into the neighbouring row -- or, for the first row of the first
+        // item, in front of the buffer.  Element loads of the nx pixels that exist; the rest stay zero.
+        // Same register layout as a chunk that straddles the row end by s = 4 - nx pixels.
+        c.s = 4 - nx;
+        const TIn* rrow = ref + (int64_t)yy * nx;
+        const TIn* mrow = img + (int64_t)(ny - 1 - yy) * nx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c.r.v[k] = k >= c.s ? rrow[k - c.s] : (TIn)0;       // r.v[s + e] = ref pixel e
+            c.t.v[k] = k < nx ? mrow[k] : (TIn)0;               // t.v[3 - s - e] = flipped-image pixel e
+        }
+        c.in = c.in && x == 0;
+        return c;
+    }
     const int xx = x < nx ? x : 0;
     int s = xx + 4 - nx;
     s = s < 0 ? 0 : s;

@@ -413,6 +413,27 @@ def test_find_displacement_variable_shapes(spx):
             assert st[-1] == 6
 
 
+def test_cutouts_narrower_than_a_load_chunk(spx):
+    """3- and 4-pixel-wide cutouts (reference mode's lower limit), first in their batch: the staging used to
+    read in front of the buffer for them (see tests/test_kernel_logic_cpu.py).  Every family, both entries."""
+    rng = np.random.default_rng(33)
+    shapes = [(50, 3), (3, 3), (3, 50), (30, 3), (64, 4), (80, 3), (3, 85), (100, 3), (128, 4), (3, 128), (130, 3)]
+    refs, ims = [], []
+    for (ny, nx) in shapes:
+        t = datagen.dither_set(ny, nx, rng.uniform(-.5, .5), rng.uniform(-.5, .5), max(0.8, min(ny, nx) / 6), 1.0,
+                               np.float32, noise_seed=5, noise_level=0.01)
+        refs.append(t[0])
+        ims.append(np.stack(t[1:]))
+    for name in ('NCC', 'ZNCC'):
+        d, st = spx.find_displacement_var(refs, ims, cc_type=name, return_status=True)
+        for k, (ny, nx) in enumerate(shapes):
+            s2 = []
+            e = orc.find_displacement(refs[k], *ims[k], cc_type=name, _status=s2)
+            assert st[k] == s2[-1] and np.max(np.abs(d[k] - np.array(e))) < 3e-5, (ny, nx, name)
+            one = spx.find_displacement_batch(refs[k][None], ims[k][None], cc_type=name)
+            assert np.max(np.abs(one[0] - d[k])) < 2e-6
+
+
 def test_find_displacement_single_call_api(spx, golden_dir):
     g = _load(golden_dir, 'find_displacement.npz')
     for tag in 'ab':

@@ -408,3 +408,30 @@ def test_variable_shape_batches():
             if max(ny, nx) > (0 if fam == 32 else 32 if fam == 64 else 64 if fam == 85 else 85):
                 # same kernel family as the uniform call would pick: bit-identical
                 assert np.array_equal(one[0], out[k]) and np.array_equal(icc1[0], iccs[k])
+
+
+def test_cutouts_narrower_than_a_load_chunk():
+    """Reference mode takes cutouts down to 3 px per side.  The branch-free staging loads 4-pixel chunks
+    and, for a chunk that straddles the row end, the row's LAST four pixels: a 3-pixel row has none, and the
+    first version read in front of the buffer (a GPU memory fault in tools/sweep_disp5.py; reproduced as a
+    heap-buffer-overflow under the harness's address sanitizer).  Rows shorter than a chunk are now read
+    pixel by pixel; results against the oracle on every family."""
+    rng = np.random.default_rng(3)
+    for fam, shapes in ((32, [(3, 3), (30, 3), (3, 31)]), (64, [(50, 3), (3, 50), (64, 4)]),
+                        (85, [(80, 3), (3, 85)]), (128, [(100, 3), (3, 128), (128, 4)])):
+        refs, ims = [], []
+        for (ny, nx) in shapes:
+            t = datagen.dither_set(ny, nx, rng.uniform(-.5, .5), rng.uniform(-.5, .5), max(0.8, min(ny, nx) / 6), 1.0,
+                                   np.float32, noise_seed=5, noise_level=0.01)
+            refs.append(t[0])
+            ims.append(np.stack(t[1:]))
+        out, st, iccs = emu.disp5_var(refs, ims, fam, 2)
+        for k in range(len(shapes)):
+            s2 = []
+            e = orc.find_displacement(refs[k], *ims[k], cc_type='ZNCC', _status=s2)
+            eicc = orc.build_icc(refs[k], *ims[k], cc_type='ZNCC')[0]
+            assert np.abs(out[k] - np.array(e)).max() < 2e-5 and st[k] == s2[-1], (fam, shapes[k])
+            assert np.abs(iccs[k] - eicc).max() < 3e-6 * np.abs(eicc).max()
+    t = datagen.dither_set(130, 3, 0.2, -0.3, 0.9, 1.0, np.float32)           # general path
+    d, st, _ = emu.disp5(t[0][None], np.stack(t[1:])[None], 1)
+    assert np.abs(d[0] - np.array(orc.find_displacement(*t, cc_type='NCC'))).max() < 2e-5

@@ -52,6 +52,13 @@ for n in (20, 64, 80, 100) if not quick else (64,):
     exp, est = orc.xcorr_refine_batch(ref.astype(np.float64), datagen.pair_batch(9, 2, n)[1].astype(np.float64), 10, 'ZNCC')
     print('nan/f64 %3d ok, f64 ZNCC max |d| %.2e' % (n, float(np.abs(got - exp).max())), flush=True)
     assert np.array_equal(st, est) and np.abs(got - exp).max() < 1e-3
+# cutouts narrower than a 4-pixel load chunk (reference mode goes down to 3 px)
+for shape in ((50, 3), (3, 50), (100, 3), (80, 3), (20, 3), (130, 3)):
+    t = datagen.dither_set(shape[0], shape[1], 0.2, -0.3, 0.9, 1.0, np.float32)
+    d, st, icc = emu.disp5(t[0][None], np.stack(t[1:])[None], 1)
+    e = orc.find_displacement(*t, cc_type='NCC')
+    assert np.abs(d[0] - np.array(e)).max() < 1e-4, shape
+print('narrow cutouts OK', flush=True)
 for n in (24, 48) if quick else (24, 48, 77, 100, 140):
     r, m4, t = datagen.dither_batch(3, 2, n)
     d, icc, st = emu.disp5(r, m4, 1)
