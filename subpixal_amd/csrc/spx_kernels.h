@@ -489,23 +489,25 @@ template <typename T> SPX_DEVICE float norm_ref(T r, const NormStatsT<T>& ns) {
 // several chunks are all in flight together (one exposed memory latency instead of one per chunk).
 // Chunks outside the cutout load a clamped (valid) address and come back as zeros; a chunk that
 // straddles the row end (nx not a multiple of 4) loads the row's LAST four pixels and shifts.
+// That needs rows of at least four pixels.  Cutouts narrower than a chunk (3 pixels: reference
+// mode's lower limit) take the NARROW instantiation -- element loads of the pixels that exist --
+// chosen by a branch AROUND the staging routine (uniform per item), never per chunk: a branch per
+// chunk serialises the loads, and a 4-element load of a 3-pixel row would start one element in
+// front of the item (a GPU memory fault for the first item of a batch; tools/sweep_disp5.py).
 // ---------------------------------------------------------------------------
 template <typename TIn> struct ChunkLoad {
     Quad<TIn> r, t;      // ref[yy][xx-s .. +3],  img[ny-1-yy][nx-4-xx+s .. +3]
     int s;               // pixels of the chunk beyond the row end (0..3)
     bool in;             // chunk starts inside the cutout
 };
-template <typename TIn>
+template <typename TIn, bool NARROW>
 SPX_DEVICE ChunkLoad<TIn> chunk_issue(const TIn* __restrict__ ref, const TIn* __restrict__ img,
                                       int ny, int nx, int y, int x) {
     ChunkLoad<TIn> c;
     c.in = y < ny && x < nx;
     const int yy = y < ny ? y : ny - 1;
-    if (nx < 4) {
-        // rows shorter than a chunk (3-pixel-wide cutouts, reference mode only; wave-uniform branch):
-        // a 4-element load would reach into the neighbouring row -- or, for the first row of the first
-        // item, in front of the buffer.  Element loads of the nx pixels that exist; the rest stay zero.
-        // Same register layout as a chunk that straddles the row end by s = 4 - nx pixels.
+    if (NARROW) {
+        // nx < 4: same register layout as a chunk that straddles the row end by s = 4 - nx pixels
         c.s = 4 - nx;
         const TIn* rrow = ref + (int64_t)yy * nx;
         const TIn* mrow = img + (int64_t)(ny - 1 - yy) * nx;
@@ -561,8 +563,8 @@ template <int C, bool FOLD> struct StageGeom {
 };
 
 // ssq[0] += sum ref^2, ssq[1] += sum img^2 over this thread's pixels (as staged).
-template <int C, bool FOLD = false, typename TIn = float>
-SPX_DEVICE void stage_pair(unsigned char* lds, const TIn* __restrict__ ref,
+template <int C, bool FOLD = false, typename TIn = float, bool NARROW = false>
+SPX_DEVICE void stage_pair_rows(unsigned char* lds, const TIn* __restrict__ ref,
                            const TIn* __restrict__ img, int ny, int nx,
                            const NormStatsT<TIn>& ns, float (&ssq)[2]) {
     typedef Lds<C> L;
@@ -610,7 +612,7 @@ SPX_DEVICE void stage_pair(unsigned char* lds, const TIn* __restrict__ ref,
         const int idx = tid + i * kThreads;
         const int y = FOLD ? idx / G::CHUNKS : idx >> 4;
         const int x = (FOLD ? idx - y * G::CHUNKS : (idx & 15)) << 2;
-        ld[i] = chunk_issue(ref, img, ny, nx, y, x);        // (rows beyond the staged region: y >= ny, zeros)
+        ld[i] = chunk_issue<TIn, NARROW>(ref, img, ny, nx, y, x);        // (rows beyond the staged region: y >= ny, zeros)
     }
 #pragma unroll
     for (int i = 0; i < kIters; ++i) {
@@ -627,6 +629,13 @@ SPX_DEVICE void stage_pair(unsigned char* lds, const TIn* __restrict__ ref,
     }
     ssq[0] = sr;
     ssq[1] = sm;
+}
+template <int C, bool FOLD = false, typename TIn = float>
+SPX_DEVICE void stage_pair(unsigned char* lds, const TIn* __restrict__ ref,
+                           const TIn* __restrict__ img, int ny, int nx,
+                           const NormStatsT<TIn>& ns, float (&ssq)[2]) {
+    if (nx < 4) stage_pair_rows<C, FOLD, TIn, true>(lds, ref, img, ny, nx, ns, ssq);     // (uniform per item)
+    else stage_pair_rows<C, FOLD, TIn, false>(lds, ref, img, ny, nx, ns, ssq);
 }
 
 // Z = FFT(ref + i*bal*flip(img)) is squared, so the cross term 2 ref*img is rounded

@@ -61,8 +61,8 @@ struct __attribute__((packed, aligned(4))) F32x4U { float v[4]; };   // 16-byte 
 // every thread issues its 16-byte loads back to back (one exposed memory latency per half),
 // then folds and stores.  The waves then fold along x themselves: v = u[x'] + w_C^cx u[x'+64].
 constexpr int kUS = 136;         // row stride (floats): 128 + 8, conflict-free 8x8 tile reads
-template <int C, typename TIn>
-SPX_DEVICE void stage_yfold(unsigned char* lds, const TIn* __restrict__ ref,
+template <int C, typename TIn, bool NARROW>
+SPX_DEVICE void stage_yfold_rows(unsigned char* lds, const TIn* __restrict__ ref,
                             const TIn* __restrict__ img, int ny, int nx,
                             const NormStatsT<TIn>& ns, float bal, int cy, float (&ssq)[2]) {
     typedef LdsBig<C> L;
@@ -83,8 +83,8 @@ SPX_DEVICE void stage_yfold(unsigned char* lds, const TIn* __restrict__ ref,
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + (4 * half + i) * kThreads;
             const int yl = idx >> 5, x = (idx & 31) << 2;
-            top[i] = chunk_issue(ref, img, ny, nx, yl, x);
-            bot[i] = chunk_issue(ref, img, ny, nx, yl + 64, x);
+            top[i] = chunk_issue<TIn, NARROW>(ref, img, ny, nx, yl, x);
+            bot[i] = chunk_issue<TIn, NARROW>(ref, img, ny, nx, yl + 64, x);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -110,6 +110,15 @@ SPX_DEVICE void stage_yfold(unsigned char* lds, const TIn* __restrict__ ref,
             *reinterpret_cast<f32x4*>(uim + yl * kUS + x) = oim;
         }
     }
+}
+
+template <int C, typename TIn>
+SPX_DEVICE void stage_yfold(unsigned char* lds, const TIn* __restrict__ ref,
+                            const TIn* __restrict__ img, int ny, int nx,
+                            const NormStatsT<TIn>& ns, float bal, int cy, float (&ssq)[2]) {
+    // cutouts narrower than a load chunk: element loads (chunk_issue), uniform per item
+    if (nx < 4) stage_yfold_rows<C, TIn, true>(lds, ref, img, ny, nx, ns, bal, cy, ssq);
+    else stage_yfold_rows<C, TIn, false>(lds, ref, img, ny, nx, ns, bal, cy, ssq);
 }
 
 // Round 0 (cy = 0) also finds the balance factor: its fold along y has w = 1, so the slab keeps

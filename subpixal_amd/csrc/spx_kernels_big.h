@@ -62,8 +62,8 @@ struct LdsGen {
 
 // one 64x64 block (sy, sx) of z = ref + i*flip(img), normalised, into the LDS staging planes;
 // returns this thread's share of sum ref^2 / sum img^2 in ssq
-template <typename TIn>
-SPX_DEVICE void stage_block_big(unsigned char* lds, const TIn* __restrict__ ref,
+template <typename TIn, bool NARROW>
+SPX_DEVICE void stage_block_big_rows(unsigned char* lds, const TIn* __restrict__ ref,
                                 const TIn* __restrict__ img, int ny, int nx, int sy, int sx,
                                 const NormStatsT<TIn>& ns, float (&ssq)[2]) {
     typedef LdsGen L;
@@ -74,7 +74,7 @@ SPX_DEVICE void stage_block_big(unsigned char* lds, const TIn* __restrict__ ref,
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + i * kThreads;
-        ld[i] = chunk_issue(ref, img, ny, nx, (idx >> 4) + 64 * sy, ((idx & 15) << 2) + 64 * sx);
+        ld[i] = chunk_issue<TIn, NARROW>(ref, img, ny, nx, (idx >> 4) + 64 * sy, ((idx & 15) << 2) + 64 * sx);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -89,6 +89,15 @@ SPX_DEVICE void stage_block_big(unsigned char* lds, const TIn* __restrict__ ref,
     }
 }
 
+template <typename TIn>
+SPX_DEVICE void stage_block_big(unsigned char* lds, const TIn* __restrict__ ref,
+                                const TIn* __restrict__ img, int ny, int nx, int sy, int sx,
+                                const NormStatsT<TIn>& ns, float (&ssq)[2]) {
+    // cutouts narrower than a load chunk: element loads (chunk_issue), uniform per item
+    if (nx < 4) stage_block_big_rows<TIn, true>(lds, ref, img, ny, nx, sy, sx, ns, ssq);
+    else stage_block_big_rows<TIn, false>(lds, ref, img, ny, nx, sy, sx, ns, ssq);
+}
+
 // sums of squares over the whole cutout (as staged) -> balance factor; one pass over the pair
 template <typename TIn>
 SPX_DEVICE float balance_big(unsigned char* lds, const TIn* __restrict__ ref,
@@ -98,7 +107,8 @@ SPX_DEVICE float balance_big(unsigned char* lds, const TIn* __restrict__ ref,
     const int chunks = (nx + 3) >> 2;
     for (int g = tid; g < ny * chunks; g += kThreads) {
         const int y = g / chunks, x = (g - y * chunks) << 2;
-        const ChunkLoad<TIn> c = chunk_issue(ref, img, ny, nx, y, x);
+        const ChunkLoad<TIn> c = nx < 4 ? chunk_issue<TIn, true>(ref, img, ny, nx, y, x)
+                                        : chunk_issue<TIn, false>(ref, img, ny, nx, y, x);
         float rr[4], mm[4];
         chunk_unpack(c, ns, rr, mm);
 #pragma unroll
