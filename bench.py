@@ -328,8 +328,9 @@ def main():
                 'compute_achieved_tflops': tf,
                 'compute_peak_tflops': F32_PEAK_TFLOPS,
                 'flops_per_pair': sum(fl) * 1e6,
-                'flops_split': 'vector %.3f + v_mfma_f32_16x16x4_f32 %.3f MFLOP per pair '
-                               '(ISA census, tools/kernel_flops.py; DESIGN.md section 5)' % fl,
+                'flops_split': 'vector %.3f + %s %.3f MFLOP per pair '
+                               '(ISA census, tools/kernel_flops.py; DESIGN.md section 5)'
+                               % (fl[0], 'v_mfma_f64_16x16x4_f64' if tile > 85 else 'v_mfma_f32_16x16x4_f32', fl[1]),
             })
         out.update({
             'max_abs_err_px_vs_truth': err,
