@@ -207,10 +207,10 @@ def main():
             dist.init_process_group(args.backend)
     on_cpu = world > 1 and args.backend != 'nccl'      # gloo rehearsal: collectives on host copies
 
-    def gather(d):
+    def gather(d, async_op=False):
         if world == 1:
-            return d
-        return spx_dist.gather_shifts(d.cpu() if on_cpu else d, n_total=n_total, dst=0)
+            return spx_dist.PendingGather(None, None, None, None, local=d) if async_op else d
+        return spx_dist.gather_shifts(d.cpu() if on_cpu else d, n_total=n_total, dst=0, async_op=async_op)
 
     # BASELINE.json configs[3]: 1e7 64x64 pairs over 8 GPUs = 1.25e6 pairs (41 GB) per GPU
     config4 = args.pairs is None and world == 8 and args.tile == TILE
@@ -248,11 +248,17 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    # every step's shifts are gathered on rank 0 (north_star: "at most an RCCL gather of the per-cutout
+    # (dx, dy) shifts"); one gather stays in flight on RCCL's stream while the next step's kernel runs
+    pending = None
     for k in range(args.steps):
         ev[k][0].record()                 # torch's current stream == the launch stream
         d = subpixal_amd.xcorr_refine_batch(ref, img, upsample=ups)
         ev[k][1].record()
-        gather(d)
+        if pending is not None:
+            pending.result()
+        pending = gather(d, async_op=True)
+    pending.result()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

@@ -7,7 +7,7 @@ under "gloo" on CPU tensors for the unit tests.
 import torch
 import torch.distributed as dist
 
-__all__ = ['shard_range', 'gather_shifts', 'xcorr_refine_sharded']
+__all__ = ['shard_range', 'gather_shifts', 'PendingGather', 'xcorr_refine_sharded']
 
 
 def shard_range(n, rank, world):
@@ -18,12 +18,36 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_shifts(local, n_total=None, dst=0, group=None):
+class PendingGather:
+    """A gather of shift blocks that has been enqueued but not waited for (``gather_shifts(...,
+    async_op=True)``).  ``result()`` waits (RCCL: the current stream waits, not the host) and returns
+    what :func:`gather_shifts` returns.  Holds the buffers the collective works on until then."""
+
+    def __init__(self, work, bufs, sizes, keep, local=None):
+        self._work, self._bufs, self._sizes, self._keep, self._local = work, bufs, sizes, keep, local
+
+    def result(self):
+        if self._local is not None:               # single process: nothing was exchanged
+            return self._local
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        self._keep = None
+        if self._bufs is None:
+            return None
+        return torch.cat([b[:hi - lo] for b, (lo, hi) in zip(self._bufs, self._sizes)], dim=0)
+
+
+def gather_shifts(local, n_total=None, dst=0, group=None, async_op=False):
     """Gather per-rank shift blocks ``local [n_r, 2]`` onto ``dst`` in rank order.
     Returns the concatenated ``[n_total, 2]`` tensor on ``dst`` and None elsewhere.
-    Blocks may differ in length by one (see :func:`shard_range`)."""
+    Blocks may differ in length by one (see :func:`shard_range`).
+
+    ``async_op=True`` returns a :class:`PendingGather` instead: the collective runs on the
+    backend's own stream while the caller enqueues the next batch's kernel; call ``result()``
+    before the gathered shifts are needed (``bench.py`` keeps one gather in flight)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return local
+        return PendingGather(None, None, None, None, local=local) if async_op else local
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if n_total is None:
@@ -38,12 +62,10 @@ def gather_shifts(local, n_total=None, dst=0, group=None):
                           dtype=local.dtype, device=local.device)
         padded = torch.cat([local, pad], dim=0)
     padded = padded.contiguous()
-    if rank == dst:
-        bufs = [torch.empty_like(padded) for _ in range(world)]
-        dist.gather(padded, gather_list=bufs, dst=dst, group=group)
-        return torch.cat([b[:hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
-    dist.gather(padded, gather_list=None, dst=dst, group=group)
-    return None
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    work = dist.gather(padded, gather_list=bufs, dst=dst, group=group, async_op=async_op)
+    pending = PendingGather(work if async_op else None, bufs, sizes, padded)
+    return pending if async_op else pending.result()
 
 
 def xcorr_refine_sharded(make_local_batch, n_total, upsample=1, cc_type='CC', dst=0,

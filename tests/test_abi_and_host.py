@@ -122,13 +122,25 @@ def make(lo, hi):
 def compute(ref, img, upsample, cc_type):      # stand-in for the GPU kernel under gloo
     return torch.from_numpy(orc.xcorr_refine_batch(ref, img, upsample, cc_type)[0])
 out = xcorr_refine_sharded(make, N, upsample=1, compute=compute)
+# the pipelined form bench.py uses: one gather in flight while the next block is computed
+from subpixal_amd.dist import gather_shifts
+lo, hi = shard_range(N, rank, world)
+pend, outs = None, []
+for rep in range(3):
+    local = compute(*make(lo, hi), 1, 'CC') + float(rep)
+    if pend is not None:
+        outs.append(pend.result())
+    pend = gather_shifts(local, n_total=N, dst=0, async_op=True)
+outs.append(pend.result())
 if rank == 0:
     full = orc.xcorr_refine_batch(*make(0, N), 1)[0]
     assert out.shape == (N, 2)
     assert np.array_equal(out.numpy(), full)
+    for rep, o in enumerate(outs):
+        assert np.array_equal(o.numpy(), full + float(rep))
     print('GLOO_OK')
 else:
-    assert out is None
+    assert out is None and all(o is None for o in outs)
 dist.destroy_process_group()
 '''
 
