@@ -153,13 +153,19 @@ def flops_per_pair(tile, upsample):
 
 def kernel_build():
     """Fingerprint of the kernel sources (ties a PMC traffic file to the build it was measured on;
-    works on the GPU box, where there is no .git)."""
+    works on the GPU box, where there is no .git).  Comments and white space do not count: the hash
+    is over the code the compiler sees."""
     import hashlib
+    import re
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, 'subpixal_amd', 'csrc')
     for name in sorted(os.listdir(csrc)):
         if name.endswith(('.h', '.hip')):
-            h.update(open(os.path.join(csrc, name), 'rb').read())
+            text = open(os.path.join(csrc, name), encoding='utf-8').read()
+            text = re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)       # block comments
+            text = re.sub(r'//[^\n]*', ' ', text)                     # line comments (no "//" inside the few string literals)
+            h.update(name.encode())
+            h.update(' '.join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -423,6 +423,24 @@ SPX_DEVICE PeakResult quad_fit_wave(float v, int lane, int x1, int y1, int imax,
     return quad_fit_finish(s0, sx, sy, sxy, sxx, syy, x1, y1, imax, jmax, nx, ny);
 }
 
+// First item of workgroup b's grid-stride walk over the batch (item = b' + k * grid).  Workgroups are
+// dealt round-robin over the 8 XCDs (observed placement, MI355X_MICROARCH.md "Workgroup dispatch":
+// blocks b and b + 8 share an L2; a speed assumption only).  b' hands each XCD RUNS OF 8 CONSECUTIVE
+// ITEMS: their 16-byte shift records fill one 128-byte line and their status words one 32-byte sector
+// in that XCD's L2 and leave it whole, instead of eight L2s each writing a fragment (the 3.1x write
+// amplification of round 1: now 1.000x).  The set of items in flight at any time is the same as for
+// b' = b, so the read side does not notice.  (Giving each XCD one long contiguous run instead
+// costs 5-9 %: eight windows a power of two apart land on the same memory channels.)  Launches that are
+// not a multiple of 64 workgroups (small batches) walk linearly.
+SPX_DEVICE int64_t first_item(int64_t b, int64_t nwg) {
+#ifdef SPX_LINEAR_WALK          // A/B measurements only (tools/gpu_walk_ab.sh)
+    return b;
+#endif
+    if (nwg & 63) return b;
+    const int64_t x = b & 7, j = b >> 3;
+    return ((j >> 3) << 6) + (x << 3) + (j & 7);
+}
+
 // the w_P^j table lives in LDS for the whole life of the workgroup
 template <int C> SPX_DEVICE void load_twiddles(unsigned char* lds, const cf* __restrict__ tw_g) {
     typedef Lds<C> L;
@@ -1406,7 +1424,7 @@ SPX_TKERNEL(256) void pair_kernel(const TIn* __restrict__ ref, const TIn* __rest
     // 1/U once, kept in scalar registers (exact for the reference's U = 2 and every power
     // of two; otherwise within one ulp of the division)
     const double inv_u = rt::read_lane(1.0 / (double)U, 0);
-    for (int64_t p = rt::block_id(); p < nbatch; p += step) {
+    for (int64_t p = first_item(rt::block_id(), step); p < nbatch; p += step) {
         const bool more = full && (p + step < nbatch);
         pair_body<C, WB, DBG, FOLD, TIn>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, tw_g, ktab,
                               out + 2 * p, status ? status + p : nullptr, lds, clk,
@@ -1638,7 +1656,7 @@ SPX_TKERNEL(256) void disp5_kernel(const TIn* __restrict__ ref, const TIn* __res
                                    double* __restrict__ out, int* __restrict__ status, ItemTable items) {
     SPX_DYN_LDS(lds);
     load_twiddles<C>(lds, tw_g);
-    for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
+    for (int64_t p = first_item(rt::block_id(), rt::grid_size()); p < nbatch; p += rt::grid_size()) {
         const ItemView it = item_view(items, p, ny, nx);
         if (!it.ok) { item_refused(out, status, p, rt::thread_id() == 0); continue; }
         disp5_body<C, FOLD, TIn>(ref + it.off, im4 + 4 * it.off, it.ny, it.nx, cc_type, tw_g,

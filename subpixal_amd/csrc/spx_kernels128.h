@@ -1,19 +1,21 @@
-// spx_kernels128.h -- the tiles above 64 pixels: 96x96 (cutouts of 65..96 pixels per side,
-// FFT period P = 192 = scipy's next_fast_len(2*96-1)) and 128x128 (97..128 pixels, P = 256;
-// BASELINE.json config 3).  Same path as spx_kernels.h, template parameter C = P / 64 (3 or 4).
+// spx_kernels128.h -- cutouts of 86..128 pixels per side (BASELINE.json config 3 is 128x128): FFT period
+// P = 192 = 3 x 64 (any P > 2n - 2 - (n-1)/2 keeps the reference's 'same' window free of aliasing;
+// DESIGN.md section 1).  Same path as spx_kernels.h with C = P / 64 = 3 classes per axis (the templates
+// also carry C = 4, period 256, which round 1 used above 96 px; only C = 3 is instantiated now).
 //
 // The padded spectrum splits into C*C classes  Z[C k'+c] = FFT64{ fold_c(z)[x'] w_P^(c x') },
 // fold_c(z)[x'] = z[x'] + w_C^c z[x'+64], w_C = exp(-2 pi i / C)  (per axis; the cutout spans at
 // most two 64-blocks), each again a 64x64 complex FFT done by one wave in registers with the
 // machinery of spx_kernels.h.  A workgroup (4 waves) runs C rounds of C classes (for C = 3 the
-// fourth wave helps staging and otherwise shadows class (cy, 0) without storing anything).  These tiles do not fit the LDS the way 64x64 does ("stresses
-// LDS tile sizing"), so the per-class results  g_c[l'] = sum_{k in c} Z[k]^2 e^{2 pi i k l'/P}
-// (complex, 64x64) go to a per-workgroup workspace that stays in L2/MALL, a radix-C pass combines
-// them into the full PxP real convolution  conv[l'+64s] = Im( sum_c conj(w_C)^(c.s) g_c[l'] ) / 2P^2
-// there, and the arg-max, the MFMA refine (period-P Dirichlet kernel, real) and the fit read from it.
+// fourth wave helps staging and otherwise shadows class (cy, 0) without storing anything).  The
+// per-class results  g_c[l'] = sum_{k in c} Z[k]^2 e^{2 pi i k l'/P}  (complex, 64x64) do not fit
+// the LDS next to a second workgroup ("stresses LDS tile sizing"): the first two rounds' planes go
+// to a per-workgroup workspace, the last round's stay in the exchange buffers; a radix-C pass
+// combines them into the full PxP real convolution  conv[l'+64s] = Im( sum_c conj(w_C)^(c.s) g_c[l'] ) / 2P^2
+// in the workspace, and the arg-max, the MFMA refine (period-P Dirichlet kernel, real, float64) and
+// the fit read from it.
 //
-// Workspace per workgroup: C*C x 2 planes of 64x64 floats + P x (P+4) floats: 772 KiB (C = 4),
-// 435 KiB (C = 3).
+// Workspace per workgroup: C*C x 2 planes of 64x64 floats + P x (P+4) floats: 435 KiB (C = 3).
 #pragma once
 
 namespace spx {
@@ -620,7 +622,7 @@ SPX_TKERNEL(256) void pair128_kernel(const TIn* __restrict__ ref, const TIn* __r
     const int64_t stride = (int64_t)ny * nx;
     PhaseClock<DBG> clk;
     clk.start();
-    for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
+    for (int64_t p = first_item(rt::block_id(), rt::grid_size()); p < nbatch; p += rt::grid_size()) {
         pair128_body<C, WB, DBG, TIn>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, ktab, out + 2 * p,
                               status ? status + p : nullptr, lds, ws, clk);
         rt::block_sync();
@@ -646,7 +648,7 @@ SPX_TKERNEL(256) void disp5_128_kernel(const TIn* __restrict__ ref, const TIn* _
     float* ws = workspace + (size_t)rt::block_id() * (L::kWsBytes / sizeof(float));
     unsigned char* scr = lds + L::SCR_OFF;
     const int ny_u = ny, nx_u = nx;
-    for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
+    for (int64_t p = first_item(rt::block_id(), rt::grid_size()); p < nbatch; p += rt::grid_size()) {
         const ItemView it = item_view(items, p, ny_u, nx_u);       // per-item shape (see spx_kernels.h)
         if (!it.ok) { item_refused(out_all, status, p, rt::thread_id() == 0); continue; }
         ny = it.ny;

@@ -461,7 +461,7 @@ SPX_TKERNEL(256) void pair32_kernel(const TIn* __restrict__ ref, const TIn* __re
     double* fit = reinterpret_cast<double*>(lds + L::SCR_OFF + wave * 256);
     const int64_t stride = (int64_t)ny * nx;
     // one pair per wave; waves of a workgroup never synchronise with each other
-    for (int64_t p = rt::block_id() * 4 + wave; p < nbatch; p += rt::grid_size() * 4)
+    for (int64_t p = first_item(rt::block_id(), rt::grid_size()) * 4 + wave; p < nbatch; p += rt::grid_size() * 4)
         pair32_wave<WB, TIn>(tw, wbuf, fit, ref + p * stride, img + p * stride, ny, nx, U, cc_type, ktab,
                         out + 2 * p, status ? status + p : nullptr);
 }
@@ -483,7 +483,7 @@ SPX_TKERNEL(256) void disp5_32_kernel(const TIn* __restrict__ ref, const TIn* __
     float* wbuf = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::wave_bytes(16));
     double* fit = reinterpret_cast<double*>(lds + L::SCR_OFF + wave * 256);
     const int ny_u = ny, nx_u = nx;
-    for (int64_t p = rt::block_id() * 4 + wave; p < nbatch; p += rt::grid_size() * 4) {
+    for (int64_t p = first_item(rt::block_id(), rt::grid_size()) * 4 + wave; p < nbatch; p += rt::grid_size() * 4) {
         const int lane = fresh_tid() & 63;
         const ItemView it = item_view(items, p, ny_u, nx_u);       // per-item shape (see spx_kernels.h)
         if (!it.ok) { item_refused(out_all, status, p, lane == 0); continue; }

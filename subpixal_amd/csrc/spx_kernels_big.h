@@ -405,7 +405,7 @@ SPX_TKERNEL(256) void pair_big_kernel(const TIn* __restrict__ ref, const TIn* __
     const float* conv = ws + G.conv_off;
     unsigned char* scr = lds + L::SCR_OFF;
     const int64_t stride = (int64_t)ny * nx;
-    for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
+    for (int64_t p = first_item(rt::block_id(), rt::grid_size()); p < nbatch; p += rt::grid_size()) {
         const TIn* r = ref + p * stride;
         const TIn* m = img + p * stride;
         const int tid = fresh_tid();
@@ -498,7 +498,7 @@ SPX_TKERNEL(256) void disp5_big_kernel(const TIn* __restrict__ ref, const TIn* _
     unsigned char* scr = lds + L::SCR_OFF;
     const int64_t stride = (int64_t)ny * nx;
     const int NX = 2 * nx, NY = 2 * ny;
-    for (int64_t p = rt::block_id(); p < nbatch; p += rt::grid_size()) {
+    for (int64_t p = first_item(rt::block_id(), rt::grid_size()); p < nbatch; p += rt::grid_size()) {
         const TIn* r = ref + p * stride;
         const TIn* m4 = im4 + 4 * p * stride;
         float* icc = icc_all + 4 * p * stride;

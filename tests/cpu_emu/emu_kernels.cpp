@@ -27,6 +27,8 @@ extern "C" int emu_lds_bytes(int U) {
 #if EMU_PART == 4
 int64_t g_grid = 0;            // 0: one workgroup per item; else grid-stride over the batch
 extern "C" void emu_set_grid(int64_t g) { g_grid = g; }
+// the kernels' workgroup -> first item mapping (spx_kernels.h), for the bijection test
+extern "C" int64_t emu_first_item(int64_t b, int64_t nwg) { return first_item(b, nwg); }
 #else
 extern int64_t g_grid;
 #endif

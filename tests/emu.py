@@ -38,6 +38,12 @@ def set_grid(g):
     lib().emu_set_grid(ctypes.c_int64(g))
 
 
+def first_item(b, nwg):
+    fn = lib().emu_first_item
+    fn.restype = ctypes.c_int64
+    return int(fn(ctypes.c_int64(b), ctypes.c_int64(nwg)))
+
+
 def _in_dtype(*arrays):
     """float64 arrays go to the float64-input kernels, everything else is float32"""
     return np.float64 if all(np.asarray(a).dtype == np.float64 for a in arrays) else np.float32

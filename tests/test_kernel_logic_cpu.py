@@ -35,6 +35,30 @@ def test_pair_mode_grid_stride_pipeline():
     assert np.array_equal(st, est)
 
 
+def test_item_walk_is_a_bijection_and_keeps_runs_of_eight_on_one_l2():
+    """first_item (spx_kernels.h): workgroup -> first item of its grid-stride walk.  Every grid size
+    must visit each item exactly once; launches of a multiple of 64 workgroups hand workgroups
+    b, b+8, ... (one XCD's, by the observed round-robin placement) runs of 8 consecutive items."""
+    for nwg in (1, 7, 63, 64, 65, 100, 128, 192, 8192):
+        seen = sorted(emu.first_item(b, nwg) for b in range(nwg))
+        assert seen == list(range(nwg)), nwg
+    for nwg in (64, 8192):
+        for x in range(8):
+            items = [emu.first_item(b, nwg) for b in range(x, nwg, 8)]
+            assert all(items[k + 1] == items[k] + 1 for k in range(len(items) - 1) if (k + 1) % 8), (nwg, x)
+            assert all(i // 8 % 8 == x for i in items)
+    # a whole launch through the remapped walk gives the per-item results of the linear one
+    ref, img, truth = datagen.pair_batch(9, 70, 40)
+    emu.set_grid(3)
+    try:
+        lin, st_lin = emu.pair(ref, img, 1)
+        emu.set_grid(64)
+        rem, st_rem = emu.pair(ref, img, 1)
+    finally:
+        emu.set_grid(0)
+    assert np.array_equal(lin, rem) and np.array_equal(st_lin, st_rem)
+
+
 def test_pair_mode_period_192():
     """cutouts of 86..128 px: period-192 path (9 classes, radix-3 fold and combine, workspace)"""
     ref, img, truth = datagen.pair_batch(5, 1, 128)
