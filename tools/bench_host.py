@@ -2,12 +2,15 @@
 """PCIe-inclusive rate of the pair path when the caller hands over HOST arrays (numpy in,
 numpy out through subpixal_amd.cc.xcorr_refine_batch): never bench.py's `value`, recorded in
 DESIGN.md section 4.  Pageable and pinned host memory."""
+import os
+import sys
 import time
 
 import numpy as np
 import torch
 
-from subpixal_amd import cc, device, synth
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from subpixal_amd import cc, device, synth      # noqa: E402
 
 N, n, U = 50000, 64, 10
 device.init()
