@@ -162,6 +162,17 @@ template <int XS> SPX_DEVICE void transpose_tile(cf (&v)[8][8], float* xch, int 
     }
 }
 
+// A class plane on its way from the tile registers to 16-byte row-contiguous stores goes through the
+// wave's exchange buffer as 64 rows of 64 floats.  Lane (l1, l0) writes rows l1 + 8 y1, columns
+// l0 + 8 x1: with a plain row stride of 64 floats all eight l1 of a column share one bank (8-way
+// conflict on every ds_write_b32: SQ_LDS_BANK_CONFLICT was 92 % of the period-192 kernel's LDS
+// cycles).  XOR-ing the 8-column group with the row's low three bits spreads them over all 64
+// banks and keeps every aligned group of 4 columns contiguous, so the 16-byte reads stay whole:
+//   float element (row, col)      -> row * 64 + (col ^ ((row & 7) << 3))
+//   float4 slot n = row * 16 + c4 -> n ^ (((n >> 4) & 7) << 1)
+SPX_DEVICE int plane_elem(int row, int col) { return row * 64 + (col ^ ((row & 7) << 3)); }
+SPX_DEVICE int plane_slot(int n) { return n ^ (((n >> 4) & 7) << 1); }
+
 // The same transposition with whole complex elements (8 bytes) in two half-tile passes: pass h
 // moves the registers R in [32 h, 32 h + 32) as 32 rows of 66 complex slots (ds_write_b64 by all
 // lanes, conflict-free), and the lanes R of that range read their row back with 32 ds_read_b128.

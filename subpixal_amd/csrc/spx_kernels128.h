@@ -259,7 +259,7 @@ SPX_DEVICE void class_round128(unsigned char* lds, const TIn* __restrict__ ref,
         for (int y1 = 0; y1 < 8; ++y1)
 #pragma unroll
             for (int x1 = 0; x1 < 8; ++x1)
-                xch[(l1 + 8 * y1) * 64 + l0 + 8 * x1] = part ? v[y1][x1].y : v[y1][x1].x;
+                xch[plane_elem(l1 + 8 * y1, l0 + 8 * x1)] = part ? v[y1][x1].y : v[y1][x1].x;
         rt::wave_sync();
         if (active && park && part == 1 && wave == 0) {      // LDS -> LDS: the idle wave's buffer
             f32x4* dst = reinterpret_cast<f32x4*>(lds + L::R_OFF + 3 * L::XCH_WAVE_BYTES);
@@ -271,7 +271,7 @@ SPX_DEVICE void class_round128(unsigned char* lds, const TIn* __restrict__ ref,
             f32x4* dst = rt::launder_lanes(reinterpret_cast<f32x4*>(g + part * kWs128PlaneFloats));
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                dst[i * 64 + lane] = reinterpret_cast<const f32x4*>(xch)[i * 64 + lane];
+                dst[i * 64 + lane] = reinterpret_cast<const f32x4*>(xch)[plane_slot(i * 64 + lane)];
         }
         rt::wave_sync();
     }
@@ -327,11 +327,11 @@ SPX_DEVICE void combine128(const unsigned char* lds, const float* __restrict__ w
             if (C == 3 && c == 0)
                 gre[c] = f32x4{0.f, 0.f, 0.f, 0.f};
             else if (C == 3 && c >= C * (C - 1))
-                gre[c] = reinterpret_cast<const f32x4*>(lds + L::R_OFF + (c - C * (C - 1)) * L::XCH_WAVE_BYTES)[i4];
+                gre[c] = reinterpret_cast<const f32x4*>(lds + L::R_OFF + (c - C * (C - 1)) * L::XCH_WAVE_BYTES)[plane_slot(i4)];
             else
                 gre[c] = reinterpret_cast<const f32x4*>(ws + (size_t)(c * 2) * kWs128PlaneFloats)[i4];
             if (C == 3 && c == C * (C - 1))
-                gim[c] = reinterpret_cast<const f32x4*>(lds + L::R_OFF + 3 * L::XCH_WAVE_BYTES)[i4];
+                gim[c] = reinterpret_cast<const f32x4*>(lds + L::R_OFF + 3 * L::XCH_WAVE_BYTES)[plane_slot(i4)];
             else
                 gim[c] = reinterpret_cast<const f32x4*>(ws + (size_t)(c * 2 + 1) * kWs128PlaneFloats)[i4];
         }

@@ -223,13 +223,13 @@ SPX_DEVICE void class_round_big(unsigned char* lds, const BigGeom& G, const TIn*
         for (int y1 = 0; y1 < 8; ++y1)
 #pragma unroll
             for (int x1 = 0; x1 < 8; ++x1)
-                xch[(l1 + 8 * y1) * 64 + l0 + 8 * x1] = part ? v[y1][x1].y : v[y1][x1].x;
+                xch[plane_elem(l1 + 8 * y1, l0 + 8 * x1)] = part ? v[y1][x1].y : v[y1][x1].x;
         rt::wave_sync();
         if (active) {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 reinterpret_cast<f32x4*>(g + part * G.plane)[i * 64 + lane] =
-                    reinterpret_cast<const f32x4*>(xch)[i * 64 + lane];
+                    reinterpret_cast<const f32x4*>(xch)[plane_slot(i * 64 + lane)];
         }
         rt::wave_sync();
     }
