@@ -529,7 +529,9 @@ template <typename TIn> struct ChunkLoad {
     int s;               // pixels of the chunk beyond the row end (0..3)
     bool in;             // chunk starts inside the cutout
 };
-template <typename TIn, bool NARROW>
+// NX4: the caller knows nx is a multiple of 4 (uniform per item): no chunk straddles a row end, the
+// shift is the constant 0 and chunk_unpack's selects fold away (a third of the staging's VALU work).
+template <typename TIn, bool NARROW, bool NX4 = false>
 SPX_DEVICE ChunkLoad<TIn> chunk_issue(const TIn* __restrict__ ref, const TIn* __restrict__ img,
                                       int ny, int nx, int y, int x) {
     ChunkLoad<TIn> c;
@@ -550,7 +552,7 @@ SPX_DEVICE ChunkLoad<TIn> chunk_issue(const TIn* __restrict__ ref, const TIn* __
     }
     const int xx = x < nx ? x : 0;
     int s = xx + 4 - nx;
-    s = s < 0 ? 0 : s;
+    s = (NX4 || s < 0) ? 0 : s;
     c.s = s;
     c.r = load_quad(ref + (int64_t)yy * nx + (xx - s));
     c.t = load_quad(img + (int64_t)(ny - 1 - yy) * nx + (nx - 4 - xx + s));
@@ -592,7 +594,7 @@ template <int C, bool FOLD> struct StageGeom {
 };
 
 // ssq[0] += sum ref^2, ssq[1] += sum img^2 over this thread's pixels (as staged).
-template <int C, bool FOLD = false, typename TIn = float, bool NARROW = false>
+template <int C, bool FOLD = false, typename TIn = float, bool NARROW = false, bool NX4 = false>
 SPX_DEVICE void stage_pair_rows(unsigned char* lds, const TIn* __restrict__ ref,
                            const TIn* __restrict__ img, int ny, int nx,
                            const NormStatsT<TIn>& ns, float (&ssq)[2]) {
@@ -641,7 +643,7 @@ SPX_DEVICE void stage_pair_rows(unsigned char* lds, const TIn* __restrict__ ref,
         const int idx = tid + i * kThreads;
         const int y = FOLD ? idx / G::CHUNKS : idx >> 4;
         const int x = (FOLD ? idx - y * G::CHUNKS : (idx & 15)) << 2;
-        ld[i] = chunk_issue<TIn, NARROW>(ref, img, ny, nx, y, x);        // (rows beyond the staged region: y >= ny, zeros)
+        ld[i] = chunk_issue<TIn, NARROW, NX4>(ref, img, ny, nx, y, x);        // (rows beyond the staged region: y >= ny, zeros)
     }
 #pragma unroll
     for (int i = 0; i < kIters; ++i) {
@@ -664,6 +666,7 @@ SPX_DEVICE void stage_pair(unsigned char* lds, const TIn* __restrict__ ref,
                            const TIn* __restrict__ img, int ny, int nx,
                            const NormStatsT<TIn>& ns, float (&ssq)[2]) {
     if (nx < 4) stage_pair_rows<C, FOLD, TIn, true>(lds, ref, img, ny, nx, ns, ssq);     // (uniform per item)
+    else if ((nx & 3) == 0) stage_pair_rows<C, FOLD, TIn, false, true>(lds, ref, img, ny, nx, ns, ssq);
     else stage_pair_rows<C, FOLD, TIn, false>(lds, ref, img, ny, nx, ns, ssq);
 }
 

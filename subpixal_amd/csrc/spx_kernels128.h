@@ -63,7 +63,7 @@ struct __attribute__((packed, aligned(4))) F32x4U { float v[4]; };   // 16-byte 
 // every thread issues its 16-byte loads back to back (one exposed memory latency per half),
 // then folds and stores.  The waves then fold along x themselves: v = u[x'] + w_C^cx u[x'+64].
 constexpr int kUS = 136;         // row stride (floats): 128 + 8, conflict-free 8x8 tile reads
-template <int C, typename TIn, bool NARROW>
+template <int C, typename TIn, bool NARROW, bool NX4 = false>
 SPX_DEVICE void stage_yfold_rows(unsigned char* lds, const TIn* __restrict__ ref,
                             const TIn* __restrict__ img, int ny, int nx,
                             const NormStatsT<TIn>& ns, float bal, int cy, float (&ssq)[2]) {
@@ -85,8 +85,8 @@ SPX_DEVICE void stage_yfold_rows(unsigned char* lds, const TIn* __restrict__ ref
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + (4 * half + i) * kThreads;
             const int yl = idx >> 5, x = (idx & 31) << 2;
-            top[i] = chunk_issue<TIn, NARROW>(ref, img, ny, nx, yl, x);
-            bot[i] = chunk_issue<TIn, NARROW>(ref, img, ny, nx, yl + 64, x);
+            top[i] = chunk_issue<TIn, NARROW, NX4>(ref, img, ny, nx, yl, x);
+            bot[i] = chunk_issue<TIn, NARROW, NX4>(ref, img, ny, nx, yl + 64, x);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -95,10 +95,12 @@ SPX_DEVICE void stage_yfold_rows(unsigned char* lds, const TIn* __restrict__ ref
             float tre[4], tim[4], bre[4], bim[4];
             chunk_unpack(top[i], ns, tre, tim);
             chunk_unpack(bot[i], ns, bre, bim);
+            if (cy == 0) {                        // sums of squares of the staged pixels (balance factor: round 0)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {        // sums of squares of the staged pixels (balance factor)
-                ssq[0] += tre[e] * tre[e] + bre[e] * bre[e];
-                ssq[1] += tim[e] * tim[e] + bim[e] * bim[e];
+                for (int e = 0; e < 4; ++e) {
+                    ssq[0] += tre[e] * tre[e] + bre[e] * bre[e];
+                    ssq[1] += tim[e] * tim[e] + bim[e] * bim[e];
+                }
             }
             f32x4 ore, oim;
 #pragma unroll
@@ -120,6 +122,7 @@ SPX_DEVICE void stage_yfold(unsigned char* lds, const TIn* __restrict__ ref,
                             const NormStatsT<TIn>& ns, float bal, int cy, float (&ssq)[2]) {
     // cutouts narrower than a load chunk: element loads (chunk_issue), uniform per item
     if (nx < 4) stage_yfold_rows<C, TIn, true>(lds, ref, img, ny, nx, ns, bal, cy, ssq);
+    else if ((nx & 3) == 0) stage_yfold_rows<C, TIn, false, true>(lds, ref, img, ny, nx, ns, bal, cy, ssq);
     else stage_yfold_rows<C, TIn, false>(lds, ref, img, ny, nx, ns, bal, cy, ssq);
 }
 

@@ -62,7 +62,7 @@ struct LdsGen {
 
 // one 64x64 block (sy, sx) of z = ref + i*flip(img), normalised, into the LDS staging planes;
 // returns this thread's share of sum ref^2 / sum img^2 in ssq
-template <typename TIn, bool NARROW>
+template <typename TIn, bool NARROW, bool NX4 = false>
 SPX_DEVICE void stage_block_big_rows(unsigned char* lds, const TIn* __restrict__ ref,
                                 const TIn* __restrict__ img, int ny, int nx, int sy, int sx,
                                 const NormStatsT<TIn>& ns, float (&ssq)[2]) {
@@ -74,7 +74,7 @@ SPX_DEVICE void stage_block_big_rows(unsigned char* lds, const TIn* __restrict__
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + i * kThreads;
-        ld[i] = chunk_issue<TIn, NARROW>(ref, img, ny, nx, (idx >> 4) + 64 * sy, ((idx & 15) << 2) + 64 * sx);
+        ld[i] = chunk_issue<TIn, NARROW, NX4>(ref, img, ny, nx, (idx >> 4) + 64 * sy, ((idx & 15) << 2) + 64 * sx);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -95,6 +95,7 @@ SPX_DEVICE void stage_block_big(unsigned char* lds, const TIn* __restrict__ ref,
                                 const NormStatsT<TIn>& ns, float (&ssq)[2]) {
     // cutouts narrower than a load chunk: element loads (chunk_issue), uniform per item
     if (nx < 4) stage_block_big_rows<TIn, true>(lds, ref, img, ny, nx, sy, sx, ns, ssq);
+    else if ((nx & 3) == 0) stage_block_big_rows<TIn, false, true>(lds, ref, img, ny, nx, sy, sx, ns, ssq);
     else stage_block_big_rows<TIn, false>(lds, ref, img, ny, nx, sy, sx, ns, ssq);
 }
 
