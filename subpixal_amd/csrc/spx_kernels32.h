@@ -363,13 +363,23 @@ template <int WB, typename TIn>
 SPX_DEVICE void pair32_wave(const cf* tw, float* wbuf, double* fit, const TIn* __restrict__ ref,
                             const TIn* __restrict__ img, int ny, int nx, int U, int cc_type,
                             const float* __restrict__ ktab, double* __restrict__ out,
-                            int* __restrict__ status) {
+                            int* __restrict__ status, const TIn* __restrict__ next_ref,
+                            const TIn* __restrict__ next_img, float& warm) {
     ny = rt::launder_uniform(ny);
     nx = rt::launder_uniform(nx);
     U = rt::launder_uniform(U);
     const int lane = fresh_tid() & 63;
     const NormStatsT<TIn> ns = norm_stats_wave(ref, img, 1, 0, ny * nx, cc_type);
+    rt::consume(warm);        // the warm-up load of this pair has landed (or was never issued)
     const float bal = cc_planes32(tw, wbuf, ref, img, ny, nx, ns);
+    // L2 warm-up of this wave's NEXT pair while the current one is in its arg-max / refine / fit
+    // tail (as in the 64 tile, spx_kernels.h: warm_next_pair): one element per 128-byte line, lanes
+    // 0..31 the reference, 32..63 the image; the value is only kept alive until the next staging
+    if (next_ref) {
+        const int off = (lane & 31) * (int)(128 / sizeof(TIn));
+        const TIn* q = (lane < 32 ? next_ref : next_img) + (off < ny * nx ? off : 0);
+        warm = (float)*q;
+    }
     const float oscale = 1.0f / ((float)(Lds32::P * Lds32::P) * bal);
     float bv;
     int bi;
@@ -461,9 +471,14 @@ SPX_TKERNEL(256) void pair32_kernel(const TIn* __restrict__ ref, const TIn* __re
     double* fit = reinterpret_cast<double*>(lds + L::SCR_OFF + wave * 256);
     const int64_t stride = (int64_t)ny * nx;
     // one pair per wave; waves of a workgroup never synchronise with each other
-    for (int64_t p = first_item(rt::block_id(), rt::grid_size()) * 4 + wave; p < nbatch; p += rt::grid_size() * 4)
+    const int64_t step = rt::grid_size() * 4;
+    float warm = 0.0f;
+    for (int64_t p = first_item(rt::block_id(), rt::grid_size()) * 4 + wave; p < nbatch; p += step) {
+        const bool more = p + step < nbatch;
         pair32_wave<WB, TIn>(tw, wbuf, fit, ref + p * stride, img + p * stride, ny, nx, U, cc_type, ktab,
-                        out + 2 * p, status ? status + p : nullptr);
+                        out + 2 * p, status ? status + p : nullptr,
+                        more ? ref + (p + step) * stride : nullptr, more ? img + (p + step) * stride : nullptr, warm);
+    }
 }
 
 // reference (5-image) mode on the 32 tile: one wave per source

@@ -8,7 +8,7 @@ cp $C/libsubpixal_hip.so gpurun_out/ab/lib_old.so
 for rep in 1 2 3; do
   for name in old new; do
     cp gpurun_out/ab/lib_$name.so $C/libsubpixal_hip.so
-    for cfg in "128 20" "96 10" "80 10" "64 10"; do set -- $cfg
+    for cfg in "32 10" "24 10" "64 10"; do set -- $cfg
       timeout -k 10 200 python bench.py --steps 30 --warmup 10 --tile $1 --upsample $2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; [print('$name rep $rep tile $1  %.4g pairs/s  kernel %.3f ms' % (d['value'], d['roofline']['kernel_ms'])) for d in [json.loads(l) for l in sys.stdin if l.startswith('{')]]" || exit 1
     done
   done
