@@ -104,6 +104,16 @@ def test_shard_range():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_gather_without_a_process_group_is_the_identity():
+    """one process (bench.py --gpus 1, the python API): nothing to exchange, sync or async"""
+    import torch
+    from subpixal_amd.dist import gather_shifts, PendingGather
+    local = torch.arange(10, dtype=torch.float64).reshape(5, 2)
+    assert gather_shifts(local) is local
+    pend = gather_shifts(local, async_op=True)
+    assert isinstance(pend, PendingGather) and pend.result() is local and pend.result() is local
+
+
 _WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
