@@ -465,7 +465,9 @@ SPX_TKERNEL(256) void pair32_kernel(const TIn* __restrict__ ref, const TIn* __re
     typedef Lds32 L;
     SPX_DYN_LDS(lds);
     load_twiddles32(lds, tw_g);
-    const int wave = rt::thread_id() >> 6;
+    // the wave index as a SCALAR: the pair pointers derived from it (this pair's and the next one's) then
+    // live in scalar registers instead of occupying -- and spilling -- vector ones
+    const int wave = rt::read_lane(rt::thread_id() >> 6, 0);
     const cf* tw = reinterpret_cast<const cf*>(lds + L::TW_OFF);
     float* wbuf = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::wave_bytes(16 * (WB > 0 ? WB : 1)));
     double* fit = reinterpret_cast<double*>(lds + L::SCR_OFF + wave * 256);
