@@ -24,7 +24,7 @@ timeout -k 10 600 bash tools/gpu_sq.sh > $O/sq.log 2>&1; tail -2 $O/sq.log
 cp gpurun_out/pmc_traffic_64_u10.json profiles/r02/pmc_traffic.json; for t in "128_u20" "80_u10" "96_u10"; do cp gpurun_out/pmc_traffic_$t.json profiles/r02/; done
 timeout -k 10 300 python bench.py > $O/bench.json 2>$O/bench.err && cut -c1-200 $O/bench.json
 timeout -k 10 200 python bench.py --tile 128 --upsample 20 --no-cpu-baseline > $O/bench_128_u20.json 2>>$O/bench.err
-for cfg in "96 10" "80 10"; do set -- $cfg
+for cfg in "96 10" "80 10" "32 10"; do set -- $cfg
   timeout -k 10 200 python bench.py --tile $1 --upsample $2 --no-cpu-baseline > $O/bench_${1}_u$2.json 2>>$O/bench.err && cut -c1-160 $O/bench_${1}_u$2.json
 done
 echo "== auxiliary"
