@@ -40,7 +40,8 @@ BYTES_PER_PAIR = 2 * TILE * TILE * 4 + 16 + 4
 #                goes through scipy for the same pair;
 #   reference -- cc.find_displacement restated (cc.py:21-95: 4 cross-correlations + interlace +
 #                find_peak per call, NCC), counted as 4 cross-correlations per call.
-# cpu_baseline.value is the same-work leg; the other two are reported beside it.
+# cpu_baseline.value is the FASTEST of the two legs that run the reference's own path (reference /
+# pair_u1); the float64 definition leg is 16-45x slower and is reported under `legs` only.
 # ---------------------------------------------------------------------------
 def _cpu_worker(args):
     seed, n_u10, n_u1, n_ref, tile, ups = args
@@ -108,47 +109,86 @@ def cpu_baseline(tile=TILE, upsample=UPSAMPLE, n_u10=1200, n_u1=3000, n_ref=2000
         res = pool.map(_cpu_worker, [(100 + i, n_u10, n_u1, n_ref, tile, upsample) for i in range(cores)])
     wall = time.perf_counter() - t0
     slow = [max(r[k] for r in res) for k in range(3)]     # slowest process per leg
-    return {
-        'value': cores * n_u10 / slow[0],
-        'unit': 'cross-correlations/s',
-        'cores': cores,
-        'kind': 'port',
-        'sample': ('same work as the GPU value: oracle.xcorr_refine (pair mode, upsample=%d, %dx%d float32 '
-                   'pairs, float64 numpy) x %d pairs on each of %d processes; rate = pairs / slowest '
-                   'process time (%.1f s); whole CPU leg %.1f s wall' % (upsample, tile, tile, n_u10, cores,
-                                                                        slow[0], wall)),
+    legs = {
+        'reference_mode': {'value': 4.0 * cores * n_ref / slow[2], 'unit': 'cross-correlations/s',
+                           'sample': 'oracle.find_displacement (cc.py:21-95 restated through scipy, NCC, float32 FFT): '
+                                     '4 cross-correlations + interlace + find_peak per call x %d calls per process'
+                                     % n_ref},
         'pair_u1': {'value': cores * n_u1 / slow[1], 'unit': 'cross-correlations/s',
                     'sample': "reference's own composition for one pair (fftconvolve 'same' + find_peak, "
                               "cc.py:114+86, float32 FFT) x %d per process" % n_u1},
-        'reference_mode': {'value': 4.0 * cores * n_ref / slow[2], 'unit': 'cross-correlations/s',
-                           'sample': 'oracle.find_displacement (cc.py:21-95 restated, NCC): 4 cross-correlations '
-                                     '+ interlace + find_peak per call x %d calls per process' % n_ref},
+        'pair_u%d_f64_definition' % upsample: {
+            'value': cores * n_u10 / slow[0], 'unit': 'cross-correlations/s',
+            'sample': 'oracle.xcorr_refine: the float64 numpy DEFINITION of the pair mode (zero-padded cross-power '
+                      'spectrum, matrix-DFT window, 5x5 fit) x %d pairs per process; same work as the GPU value '
+                      'but not a tuned CPU code: 16-45x slower than the legs above, do not read a speed-up off it'
+                      % n_u10},
+    }
+    # cpu_baseline.value = the FASTEST of the two legs that run the reference's own CPU path (scipy
+    # fftconvolve + find_peak, cc.py:114 + cc.py:86); the float64 definition leg is a sub-key only
+    best = max(('reference_mode', 'pair_u1'), key=lambda k: legs[k]['value'])
+    return {
+        'value': legs[best]['value'],
+        'unit': 'cross-correlations/s',
+        'cores': cores,
+        'kind': 'port',
+        'value_leg': best,
+        'sample': ("the reference's own CPU path restated (oracle, scipy float32 FFT), fastest of its two legs "
+                   "= '%s': %s; %dx%d float32 cutouts, %d processes, rate = work / slowest process time; whole "
+                   'CPU leg %.1f s wall' % (best, legs[best]['sample'], tile, tile, cores, wall)),
+        'legs': legs,
     }
 
 
 # ---------------------------------------------------------------------------
 # Compute roofline (SURVEY 8d "record roofline.compute_fraction alongside the HBM fraction"):
-# floating-point operations one pair EXECUTES, from the ISA of the kernel instance
-# (tools/kernel_flops.py: packed/scalar f32 VALU + f64 fit + v_mfma_f32_16x16x4_f32; DESIGN.md
-# section 5 has the derivation), against the 157.3 TFLOP/s f32 vector (= f32 MFMA) peak of
-# MI355X_MICROARCH.md.  Straight-line kernels only (32/64 tile): the period-192 kernel loops over
-# its 9 classes, for it the count is the analytic one of DESIGN.md.
+# floating-point operations one pair executes against the 157.3 TFLOP/s f32 vector (= f32 MFMA)
+# peak of MI355X_MICROARCH.md.  Nothing is hard-coded here: the figure is read from files under
+# profiles/<round>/ that carry the fingerprint of the kernel sources they were made from, and is
+# quoted only when that fingerprint is THIS build's:
+#   sq_flops_<tile>_u<U>.json -- dynamic: SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F32 + SQ_INSTS_VALU_MFMA_MOPS_F32
+#                                counter passes of this very command (tools/gpu_sq_flops.sh); preferred
+#   kernel_flops.json         -- static: ISA census of the kernel instance (tools/kernel_flops.py --json),
+#                                over-counts the branches a pair does not take; labelled "static"
 # ---------------------------------------------------------------------------
 F32_PEAK_TFLOPS = 157.3
-FLOPS_PER_PAIR = {          # (kernel family, refinement-window blocks) -> (vector, matrix) MFLOP
-    ('32', 1): (0.407, 0.197),
-    ('64', 1): (2.090, 0.655),
-    ('64fold', 1): (2.157, 0.655),
-    # period 192: 9 class transforms (3 rounds of the loop body) + folds + combine, analytic
-    # (DESIGN.md section 5); its 1344 refine MFMAs per pair are v_mfma_f64_16x16x4_f64
-    ('192', 2): (4.7, 2.75),
-}
+PROFILE_ROUNDS = ('r03', 'r02', 'r01')
 
 
-def flops_per_pair(tile, upsample):
+def kernel_family(tile, upsample):
     wb = 0 if upsample == 1 else (upsample + 5 + 15) // 16
     fam = '32' if tile <= 32 else '64' if tile <= 64 else '64fold' if tile <= 85 else '192'
-    return FLOPS_PER_PAIR.get((fam, wb))
+    return '%s:%d' % (fam, wb)
+
+
+def _profile_json(name):
+    """First profiles/<round>/<name> whose `kernel_build` is this build's fingerprint."""
+    build = kernel_build()
+    for rnd in PROFILE_ROUNDS:
+        try:
+            d = json.load(open(os.path.join(ROOT, 'profiles', rnd, name)))
+        except (OSError, ValueError):
+            continue
+        if d.get('kernel_build') == build:
+            return d, 'profiles/%s/%s' % (rnd, name)
+    return None, None
+
+
+def flops_per_pair(tile, upsample, n_local):
+    """(MFLOP per pair, split text, source) or None when no file matches this build."""
+    d, src = _profile_json('sq_flops_%d_u%d.json' % (tile, upsample))
+    if d is not None and d.get('pairs_per_launch') == n_local:
+        return (d['flop_per_pair'] / 1e6,
+                'dynamic, SQ counters: vector %.3f + matrix %.3f MFLOP per pair' % (
+                    d['vector_flop_per_pair'] / 1e6, d['matrix_flop_per_pair'] / 1e6), src)
+    d, src = _profile_json('kernel_flops.json')
+    if d is not None:
+        k = d['kernels'].get(kernel_family(tile, upsample))
+        if k is not None:
+            return (k['vector_mflop'] + k['matrix_mflop'],
+                    'static ISA census (over-counts un-taken branches): vector %.3f + matrix %.3f MFLOP per pair'
+                    % (k['vector_mflop'], k['matrix_mflop']), src)
+    return None
 
 
 def kernel_build():
@@ -169,6 +209,79 @@ def kernel_build():
     return h.hexdigest()[:16]
 
 
+REF_SOURCES = 20000             # reference-mode block: sources per launch (1.6 GB of cutouts)
+
+
+def reference_mode_block(dev, steps, warmup):
+    """cc.find_displacement (cc.py:21-95) -- the function subpixal itself calls (align.py:682-685) -- for a batch
+    of REF_SOURCES 64x64 float32 sources with their four half-pixel dithers, NCC, inputs resident in HBM:
+    displacements/s from HIP events on the launch stream.  Reported beside the headline, never in `value`."""
+    import torch
+    import subpixal_amd
+    n, N = TILE, REF_SOURCES
+    g = torch.Generator(device=dev)
+    g.manual_seed(20261004)
+    u = torch.rand((N, 4), generator=g, device=dev, dtype=torch.float64)
+    tx, ty = (2 * u[:, 0] - 1) * 3.0, (2 * u[:, 1] - 1) * 3.0
+    sig, amp = 4.0 + 2.0 * u[:, 2], 0.5 + 1.5 * u[:, 3]
+    yy, xx = torch.meshgrid(torch.arange(n, device=dev, dtype=torch.float64),
+                            torch.arange(n, device=dev, dtype=torch.float64), indexing='ij')
+    c = (n - 1) / 2.0
+
+    def spots(x0, y0):
+        r2 = (xx[None] - x0[:, None, None]) ** 2 + (yy[None] - y0[:, None, None]) ** 2
+        return (amp[:, None, None] * torch.exp(-r2 / (2.0 * sig[:, None, None] ** 2))).to(torch.float32)
+    ref = spots(torch.full_like(tx, c), torch.full_like(ty, c))
+    im4 = torch.empty((N, 4, n, n), dtype=torch.float32, device=dev)
+    # dither convention of align.py:664-676: image10(x, y) = image00(x + 1/2, y)
+    for q, (ox, oy) in enumerate(((0.0, 0.0), (0.5, 0.0), (0.0, 0.5), (0.5, 0.5))):
+        im4[:, q] = spots(c + tx - ox, c + ty - oy)
+    truth = torch.stack([tx, ty], dim=1)
+    for _ in range(max(1, warmup)):
+        d = subpixal_amd.find_displacement_batch(ref, im4, cc_type='NCC')
+    torch.cuda.synchronize()
+    err = float((d - truth).abs().max())
+    # (the reference's own 5x5 fit is biased by up to 7e-4 px at sigma = 4 px: SURVEY.md 8 a-0)
+    assert err < 2e-3, "reference mode is wrong (%g px): refusing to time" % err
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record()
+        subpixal_amd.find_displacement_batch(ref, im4, cc_type='NCC')
+        b.record()
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    bytes_per = 5 * n * n * 4 + 16 + 4
+    rate = N / (ms * 1e-3)
+    pmc, src = _profile_json('pmc_traffic_disp5_64.json')
+    traffic = pmc['hbm_bytes_per_launch'] if pmc is not None and pmc.get('sources_per_launch') == N else None
+    return {
+        'what': 'cc.find_displacement (cc.py:21-95) for a batch: 5 cutouts per source, NCC, interlaced image '
+                'written to HBM; same process, after the headline loop; NOT part of `value`',
+        'value': rate, 'unit': 'displacements/s', 'cross_correlations_per_s': 4.0 * rate,
+        'sources_per_launch': N, 'cutout': n, 'cc_type': 'NCC', 'steps': steps,
+        'kernel': 'spx::disp5_kernel<2, false, float>', 'kernel_ms': ms,
+        'bytes_per_displacement': bytes_per,
+        'achieved_GBps': rate * bytes_per / 1e9, 'frac_of_hbm_peak': rate * bytes_per / 1e9 / HBM_PEAK_GBS,
+        'traffic': traffic, 'traffic_source': src if traffic is not None else None,
+        'max_abs_err_px_vs_truth': err,
+    }
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` as typed: one child `python -m torch.distributed.run` with N ranks on
+    127.0.0.1 (a free port), stdout/stderr passed through.  Returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -177,18 +290,23 @@ def main():
     ap.add_argument('--pairs', type=int, default=None,
                     help='pairs per GPU (default 1e5 = configs[1]; at 8 GPUs 1.25e6 = configs[3], 1e7 pairs in all)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-reference-mode', action='store_true',
+                    help='skip the reference-mode (cc.find_displacement) block of the N=1 line')
     ap.add_argument('--tile', type=int, default=TILE, help='cutout side (64 = config 2, 128 = config 3)')
     ap.add_argument('--upsample', type=int, default=UPSAMPLE)
     ap.add_argument('--backend', default='nccl', help="'gloo' + --one-device rehearses the N>1 path on one GPU")
     ap.add_argument('--one-device', action='store_true', help='every rank uses cuda:0 (rehearsal only)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks as CHILD processes (one per GPU, the same
+        # command the driver uses) and relay rank 0's JSON line.  This process has not touched the GPU
+        # and never does; it only waits and exits with the children's code.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
         args.gpus = world
 
     # CPU baseline first (fork pool), before this process touches the GPU
@@ -273,24 +391,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    refmode = None
+    if rank == 0 and world == 1 and not args.no_reference_mode and tile == TILE:
+        del ref, img
+        refmode = reference_mode_block(dev, max(3, args.steps // 5), 2)
 
     if rank == 0:
         # HBM traffic of the same launch from the committed PMC passes (rocprofv3 cannot run
         # inside this process); only quoted for the configuration it was measured on
         # ... and only when that file was measured on THIS build of the kernels
+        name = 'pmc_traffic.json' if (tile == TILE and ups == UPSAMPLE) else 'pmc_traffic_%d_u%d.json' % (tile, ups)
         traffic, traffic_src = None, None
-        for rnd in ('r02', 'r01'):
-            try:
-                name = 'pmc_traffic.json' if (tile == TILE and ups == UPSAMPLE) else \
-                    'pmc_traffic_%d_u%d.json' % (tile, ups)
-                pmc = json.load(open(os.path.join(ROOT, 'profiles', rnd, name)))
-                if pmc.get('pairs_per_launch') == n_local and pmc.get('tile', TILE) == tile and \
-                        pmc.get('upsample', UPSAMPLE) == ups and pmc.get('kernel_build') == kernel_build():
-                    traffic = pmc['hbm_bytes_per_launch']
-                    traffic_src = 'profiles/%s/%s' % (rnd, name)
-                    break
-            except (OSError, ValueError, KeyError):
-                pass
+        pmc, src = _profile_json(name)
+        if pmc is not None and pmc.get('pairs_per_launch') == n_local and pmc.get('tile', TILE) == tile and \
+                pmc.get('upsample', UPSAMPLE) == ups:
+            traffic, traffic_src = pmc['hbm_bytes_per_launch'], src
         value = n_total * args.steps / elapsed
         achieved = n_local * bytes_per_pair / (kern_ms * 1e-3) / 1e9
         out = {
@@ -332,21 +447,22 @@ def main():
                 'pairs_per_launch': n_local,
             },
         }
-        fl = flops_per_pair(tile, ups)
+        fl = flops_per_pair(tile, ups, n_local)
         if fl is not None:
-            tf = sum(fl) * 1e6 * n_local / (kern_ms * 1e-3) / 1e12
+            tf = fl[0] * 1e6 * n_local / (kern_ms * 1e-3) / 1e12
             out['roofline'].update({
                 'compute_fraction': tf / F32_PEAK_TFLOPS,
                 'compute_achieved_tflops': tf,
                 'compute_peak_tflops': F32_PEAK_TFLOPS,
-                'flops_per_pair': sum(fl) * 1e6,
-                'flops_split': 'vector %.3f + %s %.3f MFLOP per pair '
-                               '(ISA census, tools/kernel_flops.py; DESIGN.md section 5)'
-                               % (fl[0], 'v_mfma_f64_16x16x4_f64' if tile > 85 else 'v_mfma_f32_16x16x4_f32', fl[1]),
+                'flops_per_pair': fl[0] * 1e6,
+                'flops_split': fl[1],
+                'flops_source': fl[2],
             })
         out.update({
             'max_abs_err_px_vs_truth': err,
         })
+        if refmode is not None:
+            out['reference_mode'] = refmode
         if cpu is not None:
             out['cpu_baseline'] = cpu
         print(json.dumps(out))

@@ -85,8 +85,10 @@ extern "C" {
 #define SPX_ST_WINDOW 4    /* fine peak not bracketed by the refinement window           */
 #define SPX_ST_FEWPTS 5    /* find_peak: fewer than 6 usable points (centroid.py:160,186,202) */
 #define SPX_ST_SHAPE 7     /* variable-shape batch: item outside the launched kernel family's sizes */
-#define SPX_ST_NONFINITE 6 /* a NaN/Inf pixel made the correlation NaN: integer position (0, 0),
-                              which is what numpy.argmax + centroid.py:171 return for it        */
+#define SPX_ST_NONFINITE 6 /* a NaN/Inf pixel made the correlation non-finite.  Pair mode: every lag is NaN,
+                              result = integer position (0, 0), what numpy.argmax + centroid.py:171 give.
+                              Reference mode: NaN ranks as the maximum as in numpy.argmax (centroid.py:114),
+                              result = integer position of the FIRST NaN/Inf of the interlaced image     */
 
 /* error codes */
 #define SPX_E_ARG (-1)        /* bad argument                              */

@@ -26,7 +26,7 @@ __all__ = ['find_linear_fit', 'iter_linear_fit', 'measure_shifts', 'measure_shif
            'usable_status', 'ST_SKIPPED']
 
 # per-source status of the measurement: the library's SPX_ST_* codes (include/subpixal_hip.h) or
-ST_SKIPPED = -1          # cutout shape outside what the kernels take (3..128 px per side): not measured
+ST_SKIPPED = -1          # cutout shape outside what the kernels take (3.._ffi.MAX_SIDE = 682 px per side): not measured
 
 
 def usable_status(status):
@@ -133,7 +133,8 @@ def measure_shifts(ref_tiles, im4_tiles, cc_type='NCC', full_output=False, retur
     array, ``im4_tiles[k]`` its four dithered blots (00, 10, 01, 11).  One launch per kernel
     family (``cc.find_displacement_var``), not per shape.  Returns ``dxdy [N, 2]`` (then the list of interlaced images with
     ``full_output``, then ``status [N]`` with ``return_status``).  A cutout whose shape the kernels
-    do not take (outside 3..128 px per side) is not measured: shift 0, status ST_SKIPPED --
+    do not take (outside 3..682 px per side; 129..682 px run on the general path) is not measured: shift 0,
+    status ST_SKIPPED --
     one oversized source must not abort the whole fit."""
     for k, r in enumerate(ref_tiles):
         shapes = {np.shape(r)} | {np.shape(b) for b in im4_tiles[k]}

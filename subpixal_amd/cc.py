@@ -45,7 +45,8 @@ def xcorr_refine_batch(ref, img, upsample=1, cc_type='CC', return_status=False):
     """Shifts of ``img[k]`` relative to ``ref[k]`` for a batch of cutout pairs.
 
     ref, img : ``[N, ny, nx]`` float32 or float64, torch CUDA tensors (used in place) or
-        numpy arrays (copied to the device).  5 <= ny, nx <= 128.  float64 pairs are masked
+        numpy arrays (copied to the device).  5 <= ny, nx <= 682 (``_ffi.MAX_SIDE``; above 128 px the
+        general path).  float64 pairs are masked
         and normalised in float64 (cc.py:131-156) before the float32 transforms.
     upsample : the cross-correlation is refined on a grid ``upsample`` times
         finer than the pixel grid before the 5x5 quadratic peak fit;
@@ -80,7 +81,9 @@ def find_displacement_batch(ref, im4, cc_type='NCC', full_output=False, return_s
     """``find_displacement`` for a batch: ``ref [N, ny, nx]``, ``im4 [N, 4, ny, nx]``
     (image00, image10, image01, image11).  Returns ``dxdy [N, 2]`` float64, plus the
     interlaced images ``icc [N, 2ny, 2nx]`` with ``full_output`` and the status
-    array with ``return_status``."""
+    array with ``return_status``.  ``icc`` has the dtype the reference's has -- that of the cutouts
+    (cc.py:121 ``np.empty(..., dtype=cc00.dtype)``): float64 for float64 cutouts, float32 otherwise; its
+    values come from the float32 transforms either way (3e-6 relative to a float64 correlation)."""
     like_torch = isinstance(ref, torch.Tensor)
     dt = _input_dtype(ref, im4)
     r = device.to_device(ref, dt)
@@ -101,7 +104,7 @@ def find_displacement_batch(ref, im4, cc_type='NCC', full_output=False, return_s
             device.ptr(status), device.ptr(icc), device.ptr(ws), ws_bytes, device.stream_ptr()))
     res = [_finish(out, like_torch)]
     if full_output:
-        res.append(_finish(icc, like_torch))
+        res.append(_finish(icc.to(dt), like_torch))          # cc.py:121: icc in the cutouts' dtype
     if return_status:
         res.append(_finish(status, like_torch))
     return res[0] if len(res) == 1 else tuple(res)
@@ -169,7 +172,7 @@ def find_displacement_var(refs, im4s, cc_type='NCC', full_output=False, return_s
             icc_h = icc.cpu().numpy()
             for j, k in enumerate(idx):
                 o, (ny, nx) = int(offs[j]), shapes[j]
-                iccs[k] = icc_h[4 * o:4 * o + 4 * ny * nx].reshape(2 * ny, 2 * nx)
+                iccs[k] = icc_h[4 * o:4 * o + 4 * ny * nx].reshape(2 * ny, 2 * nx).astype(dt, copy=False)
     for (shape, dt), idx in big.items():            # general path: one launch per shape
         ref = np.stack([np.asarray(refs[k], dtype=dt) for k in idx])
         im4 = np.stack([np.stack([np.asarray(x, dtype=dt) for x in im4s[k]]) for k in idx])

@@ -101,12 +101,24 @@ int current_tables(DeviceTables** out) {
     return 0;
 }
 
-// interpolation tables of one tile family for `upsample` (nullptr for upsample 1)
+// Lock order everywhere: g_mu, then a device's launch_mu (spx_shutdown's order).  A launch looks its
+// tables up under g_mu, takes launch_mu while still holding it and only then lets g_mu go (TableLock):
+// spx_shutdown on another thread therefore cannot free a table between the lookup and the enqueue.
+struct TableLock {
+    std::unique_lock<std::mutex> g;
+    std::unique_lock<std::mutex> launch;
+    TableLock() : g(g_mu) {}
+    void enter_launch(DeviceTables* t) {
+        launch = std::unique_lock<std::mutex>(t->launch_mu);
+        g.unlock();
+    }
+};
+
+// interpolation tables of one tile family for `upsample` (nullptr for upsample 1); caller holds g_mu
 int ktab_for(DeviceTables* t, Tile tile, int upsample, const float** out) {
     *out = nullptr;
     const int wb = spx::host::window_blocks(upsample);
     if (wb <= 0) return 0;
-    std::lock_guard<std::mutex> lk(g_mu);
     auto it = t->ktab[tile].find(upsample);
     if (it == t->ktab[tile].end()) {
         float* p = nullptr;
@@ -121,11 +133,11 @@ int ktab_for(DeviceTables* t, Tile tile, int upsample, const float** out) {
     return 0;
 }
 
-// general path (cutouts above 128 px): twiddles and tables per class count, built on first use
+// general path (cutouts above 128 px): twiddles and tables per class count, built on first use;
+// caller holds g_mu
 int big_tables_for(DeviceTables* t, int C, int upsample, const spx::cf** tw, const float** ktab) {
     *tw = nullptr;
     *ktab = nullptr;
-    std::lock_guard<std::mutex> lk(g_mu);
     auto it = t->tw_big.find(C);
     if (it == t->tw_big.end()) {
         float* p = nullptr;
@@ -381,17 +393,19 @@ int xcorr_refine(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
     a.out = out_dxdy; a.status = out_status;
     a.ws = reinterpret_cast<float*>(workspace);
     a.s = reinterpret_cast<hipStream_t>(stream);
+    TableLock lk;
+    if (!t->ready) return fail(SPX_E_ARG, "spx_shutdown() ran between the call's start and its launch");
     if (tile == TILE_BIG) {            // general path: class count and tables at run time
         const int C = spx::big_class_count(ny, nx);
         const spx::cf* tw = nullptr;
         rc = big_tables_for(t, C, upsample, &tw, &a.ktab);
         if (rc) return rc;
-        std::lock_guard<std::mutex> lk(t->launch_mu);
+        lk.enter_launch(t);
         return run_pair_general_wb<TIn>(t, wb, ref, img, a, C, tw, true);
     }
     rc = ktab_for(t, tile, upsample, &a.ktab);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(t->launch_mu);
+    lk.enter_launch(t);
     return run_pair<TIn>(t, wb, tile, ny > 64 || nx > 64, ref, img, a, true);
 }
 
@@ -419,16 +433,18 @@ int find_displacement5(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, i
     a.out = out_dxdy; a.status = out_status;
     a.ws = reinterpret_cast<float*>(wsb);
     a.s = reinterpret_cast<hipStream_t>(stream);
+    TableLock lk;
+    if (!t->ready) return fail(SPX_E_ARG, "spx_shutdown() ran between the call's start and its launch");
     if (tile_for(ny, nx) == TILE_BIG) {
         const int C = spx::big_class_count(ny, nx);
         const spx::cf* tw = nullptr;
         const float* unused = nullptr;
         rc = big_tables_for(t, C, 1, &tw, &unused);
         if (rc) return rc;
-        std::lock_guard<std::mutex> lk(t->launch_mu);
+        lk.enter_launch(t);
         return run_disp5_general<TIn>(t, ref, im4, a, C, tw, true);
     }
-    std::lock_guard<std::mutex> lk(t->launch_mu);
+    lk.enter_launch(t);
     return run_disp5<TIn>(t, tile_for(ny, nx), ny > 64 || nx > 64, ref, im4, a, true);
 }
 
@@ -460,7 +476,9 @@ int find_displacement5_var(const TIn* ref, const TIn* im4, const int64_t* item_o
     a.out = out_dxdy; a.status = out_status;
     a.ws = reinterpret_cast<float*>(workspace);
     a.s = reinterpret_cast<hipStream_t>(stream);
-    std::lock_guard<std::mutex> lk(t->launch_mu);
+    TableLock lk;
+    if (!t->ready) return fail(SPX_E_ARG, "spx_shutdown() ran between the call's start and its launch");
+    lk.enter_launch(t);
     return run_disp5<TIn>(t, tile, fold, ref, im4, a, true);
 }
 
@@ -492,9 +510,12 @@ int spx_prepare(int upsample) {
     if (rc) return rc;
     PairArgs pa = {};
     Disp5Args da = {};
-    for (int k = 0; k < NUM_TILES; ++k) {
-        const float* kt = nullptr;
-        if ((rc = ktab_for(t, (Tile)k, upsample, &kt))) return rc;
+    {
+        std::lock_guard<std::mutex> gl(g_mu);
+        for (int k = 0; k < NUM_TILES; ++k) {
+            const float* kt = nullptr;
+            if ((rc = ktab_for(t, (Tile)k, upsample, &kt))) return rc;
+        }
     }
     for (int k = 0; k < NUM_TILES; ++k) {
         std::lock_guard<std::mutex> lk(t->launch_mu);
@@ -527,6 +548,7 @@ int spx_prepare_shape(int ny, int nx, int upsample) {
     if ((rc = current_tables(&t))) return rc;
     const spx::cf* tw = nullptr;
     const float* kt = nullptr;
+    std::lock_guard<std::mutex> gl(g_mu);
     return big_tables_for(t, spx::big_class_count(ny, nx), upsample, &tw, &kt);
 }
 
@@ -550,6 +572,7 @@ int spx_shutdown(void) {
         t.tw_big.clear();
         for (auto& e : t.ktab_big) (void)hipFree(e.second);
         t.ktab_big.clear();
+        t.lds_ok.clear();
         t.ready = false;
     }
     if (have_prev) (void)hipSetDevice(prev);
@@ -598,7 +621,10 @@ int spx_diag_pair_phase(const float* ref, const float* img, int64_t nbatch, int 
     PairArgs a;
     a.nbatch = nbatch; a.ny = ny; a.nx = nx; a.U = 10; a.cc_type = 0; a.out = out_dxdy;
     a.status = out_status; a.ws = nullptr; a.s = reinterpret_cast<hipStream_t>(stream);
-    rc = ktab_for(t, TILE64, 10, &a.ktab);
+    {
+        std::lock_guard<std::mutex> gl(g_mu);
+        rc = ktab_for(t, TILE64, 10, &a.ktab);
+    }
     if (rc) return rc;
     const bool fold = ny > 64 || nx > 64;
 #define SPX_PH(k) case k: return fold ? run_pair64<1, true, float, k>(t, ref, img, a, true) \
@@ -623,7 +649,10 @@ int spx_diag_pair128_phase(const float* ref, const float* img, int64_t nbatch, i
     a.nbatch = nbatch; a.ny = ny; a.nx = nx; a.U = 20; a.cc_type = 0; a.out = out_dxdy;
     a.status = out_status; a.ws = reinterpret_cast<float*>(workspace);
     a.s = reinterpret_cast<hipStream_t>(stream);
-    rc = ktab_for(t, TILE192, 20, &a.ktab);
+    {
+        std::lock_guard<std::mutex> gl(g_mu);
+        rc = ktab_for(t, TILE192, 20, &a.ktab);
+    }
     if (rc) return rc;
     return run_pair192<2, float, 100>(t, ref, img, a, true);
 }

@@ -15,6 +15,8 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define SPX_DEVICE __device__ __forceinline__
 #define SPX_KERNEL(nthreads) extern "C" __global__ __launch_bounds__(nthreads)
 #define SPX_TKERNEL(nthreads) __global__ __launch_bounds__(nthreads, 2)
+// 512-thread workgroups, two per CU: four waves per SIMD, at most 128 VGPRs
+#define SPX_TKERNEL8(nthreads) __global__ __launch_bounds__(nthreads, 4)
 // all LDS lives in ONE dynamic region (cdna guide G17: keep the base 16-B aligned)
 #define SPX_STATIC_LDS(type, name, count) __shared__ type name[count]
 #define SPX_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
@@ -154,6 +156,30 @@ SPX_DEVICE f32x2 neg_add_pi(f32x2 d) {
     f32x2 r;
     asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,1] neg_hi:[1,0]" : "=v"(r) : "v"(d));
     return r;
+}
+
+// a * b + c per component
+SPX_DEVICE f32x2 fma_pk(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// (a.y * b.x + c.x, a.x * b.y + c.y): with b = (s, -s) this is c + s (-i) a
+SPX_DEVICE f32x2 fma_swap(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// v_permlane32_swap: lanes 32..63 of a trade places with lanes 0..31 of b, i.e. afterwards
+// a = [a_lo, b_lo], b = [a_hi, b_hi] (no LDS).  The builtin lets hipcc place the wait states the
+// instruction needs after a VALU write of either operand; its two results are taken as integers
+// first (bit-casting the vector elements directly mis-assigned the second one with ROCm 7.2).
+SPX_DEVICE void swap_halves(float& a, float& b) {
+    const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+    const auto r = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
+    const unsigned ra = r[0], rb = r[1];
+    a = __builtin_bit_cast(float, ra);
+    b = __builtin_bit_cast(float, rb);
 }
 
 // forces `v` to be materialised here (and nothing else)

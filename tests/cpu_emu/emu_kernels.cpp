@@ -7,6 +7,7 @@
 #endif
 #include "spx_rt_emu.h"
 #include "spx_kernels.h"
+#include "spx_kernels8.h"
 #if EMU_PART == 4
 #include "spx_aux_kernels.h"      // plain (non-template) kernels: one object only
 #endif
@@ -56,6 +57,29 @@ static int emu_pair64(const TIn* ref, const TIn* img, int64_t nbatch, int ny, in
     case 2: run([&] { pair_kernel<2, 2, 0, FOLD, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
     case 3: run([&] { pair_kernel<2, 3, 0, FOLD, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
     default: run([&] { pair_kernel<2, 4, 0, FOLD, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    }
+    return 0;
+}
+
+// the 64 tile on eight waves per pair (spx_kernels8.h)
+template <typename TIn>
+static int emu_pair8(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
+                     int U, int cc_type, double* out, int* status) {
+    const int wb = host::window_blocks(U);
+    std::vector<float> tw = host::make_twiddles(128);
+    std::vector<float> kt;
+    if (wb > 0) kt = host::make_ktab(128, U, 16 * wb);
+    const cf* twp = reinterpret_cast<const cf*>(tw.data());
+    const float* ktp = kt.empty() ? nullptr : kt.data();
+    auto run = [&](auto fn) {
+        rt::launch(g_grid > 0 && g_grid < nbatch ? g_grid : nbatch, w8::kT8, fn, w8::L8::total(16 * wb));
+    };
+    switch (wb) {
+    case 0: run([&] { w8::pair8_kernel<0, 0, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 1: run([&] { w8::pair8_kernel<1, 0, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 2: run([&] { w8::pair8_kernel<2, 0, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 3: run([&] { w8::pair8_kernel<3, 0, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    default: run([&] { w8::pair8_kernel<4, 0, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
     }
     return 0;
 }
@@ -131,7 +155,8 @@ static int emu_pair_general(const TIn* ref, const TIn* img, int64_t nbatch, int 
     return 0;
 }
 
-// tile: 0 = the product's choice, else force 32 / 64 / 192 / 256 (period of the big path)
+// tile: 0 = the product's choice, else force 32 / 64 / 192 / 256 (period of the big path);
+// 648 = the 64 tile's eight-wave kernel (spx_kernels8.h), 64 = its four-wave kernel
 template <typename TIn>
 static int emu_pair_t(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx, int U,
                       int cc_type, double* out, int* status, int tile) {
@@ -141,6 +166,7 @@ static int emu_pair_t(const TIn* ref, const TIn* img, int64_t nbatch, int ny, in
     if (n > 128) return emu_pair_general<TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
     if (tile == 0) tile = n <= 32 ? 32 : (n <= 85 ? 64 : 192);
     if (tile == 32 && n <= 32) return emu_pair32_t<TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
+    if (tile == 648 && n <= 64) return emu_pair8<TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
     if (tile == 64 && n <= 64) return emu_pair64<false, TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
     if (tile == 64 && n <= 85) return emu_pair64<true, TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
     if (tile == 192) return emu_pair_big<3, TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);

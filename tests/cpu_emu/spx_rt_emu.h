@@ -27,6 +27,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define SPX_DEVICE inline __attribute__((always_inline))
 #define SPX_KERNEL(nthreads) extern "C"
 #define SPX_TKERNEL(nthreads)
+#define SPX_TKERNEL8(nthreads)
 #define SPX_STATIC_LDS(type, name, count) static type name[count]
 #define SPX_DYN_LDS(name) unsigned char* name = ::spx::rt::emu().lds
 
@@ -90,6 +91,8 @@ SPX_DEVICE f32x2 add_mi(f32x2 s, f32x2 d) { return f32x2{s.x + d.y, s.y - d.x}; 
 SPX_DEVICE f32x2 add_pi(f32x2 s, f32x2 d) { return f32x2{s.x - d.y, s.y + d.x}; }
 SPX_DEVICE f32x2 neg_add_mi(f32x2 d) { return f32x2{d.y - d.x, -d.x - d.y}; }
 SPX_DEVICE f32x2 neg_add_pi(f32x2 d) { return f32x2{-d.x - d.y, d.x - d.y}; }
+SPX_DEVICE f32x2 fma_pk(f32x2 a, f32x2 b, f32x2 c) { return f32x2{std::fmaf(a.x, b.x, c.x), std::fmaf(a.y, b.y, c.y)}; }
+SPX_DEVICE f32x2 fma_swap(f32x2 a, f32x2 b, f32x2 c) { return f32x2{std::fmaf(a.y, b.x, c.x), std::fmaf(a.x, b.y, c.y)}; }
 SPX_DEVICE void consume(float v) { (void)v; }
 SPX_DEVICE void sched_fence() {}
 
@@ -130,6 +133,17 @@ template <int STEP> SPX_DEVICE int row_xchg(int v) { return shfl_lane(v, row_src
 SPX_DEVICE float read_lane(float v, int lane) { return shfl_lane(v, lane, my_wave().fa); }
 SPX_DEVICE int read_lane(int v, int lane) { return shfl_lane(v, lane, my_wave().ia); }
 SPX_DEVICE double read_lane(double v, int lane) { return shfl_lane(v, lane, my_wave().da); }
+
+// v_permlane32_swap: a = [a_lo, b_lo], b = [a_hi, b_hi]
+SPX_DEVICE void swap_halves(float& a, float& b) {
+    WaveState& w = my_wave();
+    int lane = ctx().tid & 63;
+    w.fa[lane] = a;
+    w.fb[lane] = b;
+    w.bar->arrive_and_wait();
+    if (lane < 32) b = w.fa[lane + 32]; else a = w.fb[lane - 32];
+    w.bar->arrive_and_wait();
+}
 
 SPX_DEVICE double shfl_xor(double v, int m) {
     WaveState& w = my_wave();

@@ -22,7 +22,7 @@ def lib():
     if _lib is None:
         srcs = [os.path.join(ROOT, 'tests', 'cpu_emu', f) for f in ('emu_kernels.cpp', 'spx_rt_emu.h')]
         srcs += [os.path.join(ROOT, 'subpixal_amd', 'csrc', f)
-                 for f in ('spx_kernels.h', 'spx_kernels128.h', 'spx_kernels32.h', 'spx_aux_kernels.h', 'spx_tables.h')]
+                 for f in sorted(os.listdir(os.path.join(ROOT, 'subpixal_amd', 'csrc'))) if f.endswith('.h')]
         if not os.environ.get('SPX_EMU_LIB') and (
                 not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs)):
             subprocess.check_call(['make', '-C', os.path.join(ROOT, 'subpixal_amd', 'csrc'), 'emu'])
