@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libsubpixal_hip.so')
+# SPX_HIP_LIB: another build of the same library (A/B measurements only: tools/gpu_r3_variants.sh)
+LIB_PATH = os.environ.get('SPX_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libsubpixal_hip.so')
 
 ABI_VERSION = 2
 MAX_SIDE = 682

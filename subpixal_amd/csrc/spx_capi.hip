@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC spx_capi.hip
 #include "spx_rt_hip.h"
 #include "spx_kernels.h"
+#include "spx_kernels8.h"
 #include "spx_kernels128.h"
 #include "spx_kernels_big.h"
 #include "spx_kernels32.h"
@@ -15,6 +16,10 @@
 #include <set>
 #include <string>
 #include <vector>
+
+#ifndef SPX_PAIR64_WAVES_DEFAULT
+#define SPX_PAIR64_WAVES_DEFAULT 4      // measured: 25.2e6 pairs/s on 4 waves, 18.2e6 on 8 (profiles/r03)
+#endif
 
 namespace {
 
@@ -231,6 +236,27 @@ int run_pair64(DeviceTables* t, const TIn* ref, const TIn* img, const PairArgs& 
     SPX_HIP(hipGetLastError());
     return 0;
 }
+// the same tile on eight waves per pair (spx_kernels8.h; cutouts up to 64 px, no fold path)
+template <int WB, typename TIn, int DBG = 0>
+int run_pair64_w8(DeviceTables* t, const TIn* ref, const TIn* img, const PairArgs& a, bool launch) {
+    const int lds = spx::w8::L8::total(16 * WB);
+    auto kern = spx::w8::pair8_kernel<WB, DBG, TIn>;
+    int rc = allow_lds(t, kern, lds);
+    if (rc || !launch) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid_for(t, a.nbatch)), dim3(spx::w8::kT8), lds, a.s, ref, img,
+                       a.nbatch, a.ny, a.nx, a.U, a.cc_type, t->tw[TILE64], a.ktab, a.out, a.status);
+    SPX_HIP(hipGetLastError());
+    return 0;
+}
+// SPX_PAIR64_WAVES = 4 | 8 (A/B knob; read once): which kernel takes pair-mode cutouts of 33..64 px
+int pair64_waves() {
+    static const int w = [] {
+        const char* e = getenv("SPX_PAIR64_WAVES");
+        const int v = e ? atoi(e) : SPX_PAIR64_WAVES_DEFAULT;
+        return v == 4 ? 4 : 8;
+    }();
+    return w;
+}
 // 32 tile: one wave per pair, four pairs per workgroup
 template <int WB, typename TIn>
 int run_pair32(DeviceTables* t, const TIn* ref, const TIn* img, const PairArgs& a, bool launch) {
@@ -262,8 +288,16 @@ int run_pair_wb(DeviceTables* t, Tile tile, bool fold, const TIn* ref, const TIn
                 const PairArgs& a, bool launch) {
     switch (tile) {
     case TILE32: return run_pair32<WB, TIn>(t, ref, img, a, launch);
-    case TILE64: return fold ? run_pair64<WB, true, TIn>(t, ref, img, a, launch)
-                             : run_pair64<WB, false, TIn>(t, ref, img, a, launch);
+    case TILE64:
+        if (fold) return run_pair64<WB, true, TIn>(t, ref, img, a, launch);
+        if constexpr (sizeof(TIn) == 4) {      // the eight-wave A/B kernel is built for float32 cutouts only
+            if (!launch) {          // spx_prepare: both variants stay launchable inside a capture
+                const int rc = run_pair64_w8<WB, TIn>(t, ref, img, a, false);
+                return rc ? rc : run_pair64<WB, false, TIn>(t, ref, img, a, false);
+            }
+            if (pair64_waves() == 8) return run_pair64_w8<WB, TIn>(t, ref, img, a, true);
+        }
+        return run_pair64<WB, false, TIn>(t, ref, img, a, launch);
     default: return run_pair192<WB, TIn>(t, ref, img, a, launch);
     }
 }
@@ -629,6 +663,10 @@ int spx_diag_pair_phase(const float* ref, const float* img, int64_t nbatch, int 
     const bool fold = ny > 64 || nx > 64;
 #define SPX_PH(k) case k: return fold ? run_pair64<1, true, float, k>(t, ref, img, a, true) \
                                       : run_pair64<1, false, float, k>(t, ref, img, a, true);
+    // phases 200 + k: the eight-wave kernel (k = 1 staging only, 10 through the planes, 100 stamps)
+    if (phase == 201) return run_pair64_w8<1, float, 1>(t, ref, img, a, true);
+    if (phase == 210) return run_pair64_w8<1, float, 10>(t, ref, img, a, true);
+    if (phase == 300) return run_pair64_w8<1, float, 100>(t, ref, img, a, true);
     switch (phase) {
         SPX_PH(0) SPX_PH(1) SPX_PH(2) SPX_PH(3) SPX_PH(4) SPX_PH(5) SPX_PH(6) SPX_PH(7)
         SPX_PH(8) SPX_PH(9) SPX_PH(10) SPX_PH(11) SPX_PH(12) SPX_PH(13) SPX_PH(100)

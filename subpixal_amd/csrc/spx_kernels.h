@@ -112,6 +112,10 @@ SPX_DEVICE void fft4(cf c0, cf c1, cf c2, cf c3, cf& y0, cf& y1, cf& y2, cf& y3)
 
 // 8-point DFT, natural order in and out (radix-2 DIF + two radix-4):
 // X[k] = sum_j a[j] e^{-DIR 2 pi i j k / 8}
+// (Round 3 tried folding the two multiplications by h into fused multiply-adds of the last stage -- 26 packed
+// instructions instead of 28, SQ_INSTS_VALU 4130 -> 4074 per wave-pair: no gain on the four-wave kernel, 5 % slower
+// on the eight-wave one, profiles/r03/variants_pt_ftfirst_w8_nowarm.txt; the constants then ride in scalar
+// register pairs of every v_pk_fma.  Dropped.)
 template <int DIR> SPX_DEVICE void fft8(cf (&a)[8]) {
     const float h = 0.70710678118654752440f;
     const cf b0 = a[0] + a[4], d4 = a[0] - a[4];
@@ -767,6 +771,7 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
         }
     rt::block_sync_lds();                       // all waves have read the staged input
     clk.tick(1);
+    rt::set_prio<0>();                          // the transforms are throughput work
 
     // class pre-twiddle w_P^{c (8 y1)} (the free radix-2 stage of the zero pad)
     if (cy) {
@@ -853,6 +858,7 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
     fft8_x<-1>(v);
     SPX_DBG_STOP(9);
     clk.tick(9);
+    rt::set_prio<1>();                          // plane write, arg-max, refine, fit: latency-bound
     // class post-twiddle conj(w_P^{8 (cy y1 + cx x1)}); the imaginary part is kept (the factor
     // 1/2 of conv = Im(IFFT(Z^2))/2 is folded into the readers' output scale).
     // The plane goes into this wave's own exchange buffer (its reads above are done).
@@ -1320,12 +1326,15 @@ SPX_DEVICE void pair_body(const TIn* __restrict__ ref, const TIn* __restrict__ i
     const int rot = (C * C - fit_wave) & (C * C - 1);     // the fitting wave takes the lightest class (0,0)
     if (cc_planes<C, DBG, FOLD>(lds, bal, clk, rot)) return;
     if constexpr (DBG == 10) return;
-    // pull the next pair into L2 while this one is in its tail
-    if constexpr (sizeof(TIn) == 4) if (next_ref) warm = warm_next_pair(next_ref, next_img);
-
-    // the refine stage's constant operands: issue the loads now, use them after the arg-max
+    // the refine stage's constant operands: issue the loads now, use them after the arg-max -- and BEFORE the
+    // warm-up below: vmcnt counts in issue order, so a wait for the tables must not include the warm-up's
+    // trip to HBM (+1.3 %, profiles/r03/variants_*.txt)
     FineTables<(WB > 0 ? WB : 1)> ft;
     if constexpr (WB > 0) load_fine_tables<C, WB>(ft, ktab, rot);
+    // pull the next pair into L2 while this one is in its tail (issuing it before the transforms instead
+    // was measured 2 % slower)
+    if constexpr (sizeof(TIn) == 4) if (next_ref) warm = warm_next_pair(next_ref, next_img);
+
     // coarse arg-max over the flipped 'same' window (centroid.py:114-116)
     float bv;
     int bi;

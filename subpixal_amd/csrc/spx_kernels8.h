@@ -408,6 +408,7 @@ SPX_DEVICE void planes8(unsigned char* lds, PhaseClock<DBG>& clk, int rot) {
     }
     rt::block_sync_lds();                      // all waves have read the staged input
     clk.tick(1);
+    rt::set_prio<0>();
 
     // ---- forward round A: lane (ya, xa), registers (yb, xb)
     class_twiddle<false>(tw, cy, cx, v);
@@ -459,6 +460,7 @@ SPX_DEVICE void planes8(unsigned char* lds, PhaseClock<DBG>& clk, int rot) {
     fft_8x4<-1>(v);                            // -> (yb, xb)
     class_twiddle<true>(tw, cy, cx, v);        // E_c[ya + 4 yb][xa + 8 xb]
     clk.tick(9);
+    rt::set_prio<1>();
 
     // ---- recombination (recombine8): what this wave keeps (`own`) and what it sends (`snd`)
     float own[32], snd[32];
@@ -742,10 +744,13 @@ SPX_DEVICE void pair8_body(const TIn* __restrict__ ref, const TIn* __restrict__ 
     const int rot = (8 - fit_wave) & 7;         // the fitting wave takes role 0 (cy = 0: no class twiddles)
     planes8<DBG>(lds, clk, rot);
     if constexpr (DBG == 10) return;
-    if constexpr (sizeof(TIn) == 4) if (next_ref) warm = warm_next_pair8(next_ref, next_img);
-
+    // the refine stage's constant operands first, the L2 warm-up of the next pair second: a wait for the
+    // tables (vmcnt counts in issue order) then does not also wait for the warm-up's trip to HBM
     FineTables8<(WB > 0 ? WB : 1)> ft;
     if constexpr (WB > 0) load_fine_tables8<WB>(ft, ktab, rot);
+#ifndef SPX8_NO_WARM
+    if constexpr (sizeof(TIn) == 4) if (next_ref) warm = warm_next_pair8(next_ref, next_img);
+#endif
     float bv;
     int bi;
     coarse_argmax8(lds, ny, nx, bv, bi);

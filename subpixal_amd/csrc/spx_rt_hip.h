@@ -182,6 +182,18 @@ SPX_DEVICE void swap_halves(float& a, float& b) {
     b = __builtin_bit_cast(float, rb);
 }
 
+// Wave priority for instruction arbitration inside a SIMD (s_setprio; 0 = default, 3 = highest).  The
+// latency-bound phases of a pair (staging, arg-max, refine, fit: few instructions, each waiting on LDS or a
+// barrier) run at SPX_PRIO_TAIL so that they are not queued behind the other workgroup's VALU-dense
+// transform phases (-DSPX_PRIO_TAIL=0 builds the kernels without it: A/B knob, profiles/r03).
+#ifndef SPX_PRIO_TAIL
+#define SPX_PRIO_TAIL 2          // measured +2.2 % on the 64 tile (profiles/r03/variants_prio_tail_prio_xform.txt)
+#endif
+#ifndef SPX_PRIO_XFORM
+#define SPX_PRIO_XFORM 0
+#endif
+template <int P> SPX_DEVICE void set_prio() { __builtin_amdgcn_s_setprio(P ? SPX_PRIO_TAIL : SPX_PRIO_XFORM); }
+
 // forces `v` to be materialised here (and nothing else)
 SPX_DEVICE void consume(float v) { asm volatile("" ::"v"(v)); }
 

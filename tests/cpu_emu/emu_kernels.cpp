@@ -166,7 +166,8 @@ static int emu_pair_t(const TIn* ref, const TIn* img, int64_t nbatch, int ny, in
     if (n > 128) return emu_pair_general<TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
     if (tile == 0) tile = n <= 32 ? 32 : (n <= 85 ? 64 : 192);
     if (tile == 32 && n <= 32) return emu_pair32_t<TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
-    if (tile == 648 && n <= 64) return emu_pair8<TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
+    if constexpr (sizeof(TIn) == 4)       // (as the product library: float32 cutouts only)
+        if (tile == 648 && n <= 64) return emu_pair8<TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
     if (tile == 64 && n <= 64) return emu_pair64<false, TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
     if (tile == 64 && n <= 85) return emu_pair64<true, TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
     if (tile == 192) return emu_pair_big<3, TIn>(ref, img, nbatch, ny, nx, U, cc_type, out, status);

@@ -93,6 +93,7 @@ SPX_DEVICE f32x2 neg_add_mi(f32x2 d) { return f32x2{d.y - d.x, -d.x - d.y}; }
 SPX_DEVICE f32x2 neg_add_pi(f32x2 d) { return f32x2{-d.x - d.y, d.x - d.y}; }
 SPX_DEVICE f32x2 fma_pk(f32x2 a, f32x2 b, f32x2 c) { return f32x2{std::fmaf(a.x, b.x, c.x), std::fmaf(a.y, b.y, c.y)}; }
 SPX_DEVICE f32x2 fma_swap(f32x2 a, f32x2 b, f32x2 c) { return f32x2{std::fmaf(a.y, b.x, c.x), std::fmaf(a.x, b.y, c.y)}; }
+template <int P> SPX_DEVICE void set_prio() {}
 SPX_DEVICE void consume(float v) { (void)v; }
 SPX_DEVICE void sched_fence() {}
 

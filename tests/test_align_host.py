@@ -103,3 +103,38 @@ def test_zero_weight_points_are_not_measurements():
         iter_linear_fit(xy[:3], uv[:3], wuv=np.array([1.0, 0.0, 0.0]), fitgeom='general')
     st = np.array([0, 1, 2, 3, 4, 5, 6, ST_SKIPPED])
     assert list(usable_status(st)) == [True, True, True, True, False, False, False, False]
+
+
+def test_host_fit_against_the_oracles_independent_restatement():
+    """SURVEY 8 f-4 / VERDICT r2 item 9: `subpixal_amd.align.iter_linear_fit` against
+    `oracle.iter_linear_fit`, an independent restatement (augmented lstsq, Procrustes/SVD) of the documented
+    behaviour of `tweakwcs.linearfit.iter_linear_fit` (align.py:720-724).  tweakwcs itself is absent and the
+    reference holds no fixture for it: parity WITH TWEAKWCS stays unpinned; this pins the host code against
+    a second implementation of the same definition."""
+    from oracle import subpixal_oracle as orc
+    rng = np.random.default_rng(11)
+    c = np.array([2048.0, 2048.0])
+    th = np.radians(0.02)
+    truths = {
+        'shift': (np.eye(2), np.array([0.37, -1.21])),
+        'rscale': (1.0003 * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]), np.array([-0.5, 0.25])),
+        'general': (np.array([[1.0003, 2e-5], [-4e-5, 0.9998]]), np.array([1.5, -0.75])),
+    }
+    for geom, (f, t) in truths.items():
+        for trial in range(4):
+            n = int(rng.integers(40, 400))
+            xy = rng.uniform(0, 4096, (n, 2))
+            uv = (xy - c) @ f.T + c + t + 0.02 * rng.standard_normal((n, 2))
+            bad = rng.choice(n, n // 15, replace=False)
+            uv[bad] += rng.uniform(-8, 8, (len(bad), 2))
+            w = rng.uniform(0.2, 3.0, n) if trial % 2 else None
+            if w is not None and trial == 3:
+                w[rng.choice(n, 5, replace=False)] = 0.0          # not measurements
+            got = iter_linear_fit(xy, uv, wuv=w, fitgeom=geom, center=c, nclip=3, sigma=3.0)
+            ef, et, emask, eclip = orc.iter_linear_fit(xy, uv, wuv=w, fitgeom=geom, center=c, nclip=3, sigma=3.0)
+            assert np.array_equal(got['fitmask'], emask), (geom, trial)
+            assert got['eff_nclip'] == eclip
+            np.testing.assert_allclose(got['fit_matrix'], ef, atol=1e-11, rtol=0)
+            np.testing.assert_allclose(got['offset'], et, atol=1e-8, rtol=0)
+            np.testing.assert_allclose(got['fit_matrix'], f, atol=2e-5)
+            np.testing.assert_allclose(got['offset'], t, atol=2e-2)

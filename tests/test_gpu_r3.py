@@ -1,0 +1,120 @@
+"""Round-3 parity tests (`-m gpu`): the two carve-outs of the round-2 sweeps as tests, and the
+eight-wave A/B kernel of the 64 tile through the C-ABI."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import datagen
+from oracle import subpixal_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def spx():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import subpixal_amd
+    return subpixal_amd
+
+
+def _catalog(rng, count, wide):
+    """sources of one shape each; `wide`: 100..140 px cutouts with spots of n/10..n/6 px -- the kind on
+    which the reference's own 5x5 fit is ill-conditioned (centroid.py:219-234 accepts the quadratic's
+    stationary point anywhere inside the image; tools/sweep_disp5.py set 10 of 115,200 such sources apart)"""
+    refs, ims = [], []
+    for _ in range(count):
+        if wide:
+            ny, nx = int(rng.integers(96, 141)), int(rng.integers(93, 141))
+            sigma = min(ny, nx) / rng.uniform(6, 10)
+        else:
+            ny, nx = int(rng.integers(3, 129)), int(rng.integers(3, 129))
+            sigma = max(0.8, min(ny, nx) / rng.uniform(8, 14))
+        smax = min(2.0, min(ny, nx) / 6.0)
+        dt = np.float64 if rng.random() < 0.3 else np.float32
+        t = datagen.dither_set(ny, nx, rng.uniform(-smax, smax), rng.uniform(-smax, smax), sigma,
+                               rng.uniform(0.5, 2.0), dt, int(rng.integers(1, 1 << 30)) if rng.random() < 0.7 else 0,
+                               float(rng.choice([0.003, 0.02])), int(rng.choice([0, 0, 1, 2])) if min(ny, nx) >= 12 else 0)
+        refs.append(t[0])
+        ims.append(np.stack(t[1:]))
+    return refs, ims
+
+
+def test_fit_stage_is_exact_on_the_gpus_own_interlaced_image(spx):
+    """centroid.find_peak (centroid.py:18-236 with cc.py:86's arguments) applied by the ORACLE to the
+    interlaced image the GPU returned (full_output) must give the GPU's (dx, dy, status): that proves the
+    arg-max + fit + every early return exact, so that any difference to the float64 reference path is the
+    3e-7 relative noise of the float32 transforms in the image -- including the sources whose fit is
+    ill-conditioned in the reference itself (stationary point outside the 5x5 box it was fitted on)."""
+    rng = np.random.default_rng(20261004)
+    outside = 0
+    for name, wide in (('CC', False), ('NCC', False), ('ZNCC', False), ('CC', True), ('NCC', True), ('ZNCC', True)):
+        refs, ims = _catalog(rng, 64, wide)
+        d, iccs, st = spx.find_displacement_var(refs, ims, cc_type=name, full_output=True, return_status=True)
+        for k in range(len(refs)):
+            icc = np.asarray(iccs[k], np.float64)           # the GPU's float32 values, exactly
+            s2 = []
+            xm, ym = orc.find_peak(icc, peak_fit_box=5, peak_search_box='all', _status=s2)
+            ex = 0.5 * xm - (icc.shape[1] - 1) // 4         # cc.py:89-93
+            ey = 0.5 * ym - (icc.shape[0] - 1) // 4
+            assert st[k] == s2[-1], (k, name, refs[k].shape, st[k], s2[-1])
+            # the same box through the constant operator the kernel implements
+            x5, y5, s5 = orc.find_peak_5x5_all(icc)
+            assert s5 == st[k]
+            jm, im_ = np.unravel_index(int(np.argmax(icc)), icc.shape)
+            far = max(abs(xm - im_), abs(ym - jm)) > 2.5   # vertex outside the box it was fitted on
+            outside += bool(far)
+            # float64 against float64: 1e-9 px; a vertex far outside its box is a ratio of two nearly
+            # cancelling float64 quantities, where two correct float64 evaluations differ by more
+            tol = 1e-6 if far else 1e-9
+            assert abs(d[k, 0] - (0.5 * x5 - (icc.shape[1] - 1) // 4)) <= tol, (k, name, refs[k].shape)
+            assert abs(d[k, 1] - (0.5 * y5 - (icc.shape[0] - 1) // 4)) <= tol, (k, name, refs[k].shape)
+            assert abs(d[k, 0] - ex) <= 100 * tol and abs(d[k, 1] - ey) <= 100 * tol, (k, name, refs[k].shape)
+    print('sources with the fitted maximum outside its 5x5 box: %d of 384' % outside)
+
+
+_EIGHT_WAVE_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + '/tests')
+import datagen, subpixal_amd as spx
+from subpixal_amd import synth
+from oracle import subpixal_oracle as orc
+for up, tol in ((1, 1e-5), (2, 2e-5), (10, 2e-4), (20, 2e-4)):
+    ref, img, truth = datagen.pair_batch(21, 24, 64)
+    got, st = spx.xcorr_refine_batch(ref, img, upsample=up, return_status=True)
+    exp, est = orc.xcorr_refine_batch(ref, img, up)
+    assert np.max(np.abs(got - exp)) < tol, (up, np.max(np.abs(got - exp)))
+    assert np.array_equal(st, est)
+rng = np.random.default_rng(5)
+for ny, nx, up, name in ((63, 61, 10, 'NCC'), (40, 57, 2, 'ZNCC'), (5, 5, 1, 'CC'), (64, 37, 30, 'NCC'), (33, 64, 45, 'CC')):
+    r = np.empty((6, ny, nx), np.float32); i = np.empty_like(r)
+    for k in range(6):
+        tx, ty = rng.uniform(-2, 2, 2) if min(ny, nx) > 8 else rng.uniform(-0.5, 0.5, 2)
+        r[k], i[k] = datagen.pair_set(ny, nx, tx, ty, rng.uniform(1.2, min(ny, nx) / 8 + 1.2), 1.3, np.float32,
+                                      noise_seed=int(rng.integers(1, 1000)), noise_level=0.01)
+    got, st = spx.xcorr_refine_batch(r, i, upsample=up, cc_type=name, return_status=True)
+    exp, est = orc.xcorr_refine_batch(r, i, up, name)
+    assert np.max(np.abs(got - exp)) < 3e-4 and np.array_equal(st, est), (ny, nx, up, name)
+ref, img, truth = synth.gaussian_pairs(30000, 64, seed=99)
+d1, st = spx.xcorr_refine_batch(ref, img, upsample=10, return_status=True)
+assert float((d1 - truth).abs().max()) < 1e-3 and int(st.abs().max()) == 0
+assert torch.equal(d1, spx.xcorr_refine_batch(ref, img, upsample=10))
+perm = torch.randperm(30000, device=ref.device)[:5000]
+assert torch.equal(spx.xcorr_refine_batch(ref[perm].contiguous(), img[perm].contiguous(), upsample=10), d1[perm])
+print('eight-wave kernel OK')
+'''
+
+
+def test_eight_wave_kernel_through_the_c_abi(spx):
+    """SPX_PAIR64_WAVES=8 (read once per process, hence the child): the 16-class / half-wave kernel of
+    spx_kernels8.h against the oracle on full and ragged tiles, every cc_type and window size, plus
+    truth / determinism / permutation properties on 3e4 device-generated pairs."""
+    env = dict(os.environ, SPX_PAIR64_WAVES='8')
+    out = subprocess.run([sys.executable, '-c', _EIGHT_WAVE_CHILD % {'root': ROOT}], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert 'eight-wave kernel OK' in out.stdout

@@ -35,6 +35,38 @@ def test_pair_mode_grid_stride_pipeline():
     assert np.array_equal(st, est)
 
 
+def test_pair_mode_eight_wave_kernel():
+    """spx_kernels8.h (round 3 A/B, SPX_PAIR64_WAVES=8): 16 mod-4 classes in half-waves, recombined into
+    the four parity planes -- same results as the four-wave kernel to float32 rounding, ragged shapes,
+    every cc_type, pairs following each other inside one workgroup"""
+    ref, img, truth = datagen.pair_batch(3, 3, 64)
+    for up, tol in ((1, 5e-6), (10, 1e-4)):
+        got, st = emu.pair(ref, img, up, tile=648)
+        exp, est = orc.xcorr_refine_batch(ref, img, up)
+        assert np.max(np.abs(got - exp)) < tol, (up, np.max(np.abs(got - exp)))
+        assert np.array_equal(st, est)
+        four, _ = emu.pair(ref, img, up, tile=64)
+        assert np.max(np.abs(got - four)) < tol
+    rng = np.random.default_rng(3)
+    emu.set_grid(2)
+    try:
+        for ny, nx, up, cc in ((63, 61, 10, 1), (40, 57, 2, 2), (5, 5, 1, 0), (64, 37, 30, 1), (7, 64, 10, 0)):
+            r = np.empty((5, ny, nx), np.float32)
+            i = np.empty_like(r)
+            for k in range(5):
+                tx, ty = rng.uniform(-2, 2, 2) if min(ny, nx) > 8 else rng.uniform(-0.5, 0.5, 2)
+                r[k], i[k] = datagen.pair_set(ny, nx, tx, ty, rng.uniform(1.2, min(ny, nx) / 8 + 1.2), 1.3,
+                                              np.float32, noise_seed=int(rng.integers(1, 1000)), noise_level=0.01)
+            got, st = emu.pair(r, i, up, cc, tile=648)
+            exp, est = orc.xcorr_refine_batch(r, i, upsample=up, cc_type=datagen.CC_TYPES[cc])
+            assert np.max(np.abs(got - exp)) < 2e-4 and np.array_equal(st, est), (ny, nx, up, cc)
+    finally:
+        emu.set_grid(0)
+    ref[0, 5, 5] = np.nan
+    got, st = emu.pair(ref, img, 10, tile=648)
+    assert st[0] == 6 and st[1] == 0 and got[0, 0] == -31.0
+
+
 def test_item_walk_is_a_bijection_and_keeps_runs_of_eight_on_one_l2():
     """first_item (spx_kernels.h): workgroup -> first item of its grid-stride walk.  Every grid size
     must visit each item exactly once; launches of a multiple of 64 workgroups hand workgroups

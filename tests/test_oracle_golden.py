@@ -203,3 +203,42 @@ def test_pair_u10_within_1e3_of_reference(golden_dir):
         # and it is closer to the truth than the reference's own fit bias
         assert np.max(np.abs(np.array(got) - p[k, :2])) < 2e-4
     assert worst < 1e-3, worst
+
+
+def test_pair_mode_period_is_pinned_by_an_independent_interpolant():
+    """for cutouts of 65..128 px the oracle's FFT period (128 up to 85 px, 192 up to 128 px:
+    `fft_period`) was chosen together with the kernels, and between the integer lags the period enters the
+    DEFINITION of the pair mode's interpolant.  Independent check: the full linear cross-correlation by
+    direct summation (no FFT, no period), placed on a period-512 grid and interpolated there, must give the
+    same sub-pixel shift -- to 1e-8 px on noise-free spots, BASELINE.json's parity set (the interpolants of
+    a smooth peak agree whatever the period).  With 2 % pixel noise the interpolant between the integer lags
+    does depend on the period, at the 1e-3 px level (measured here: up to 1.5e-3 px between periods 192 and
+    512 at 128 px, bound 3e-3) -- far below what that noise does to the peak itself (~2e-2 px), and the reason
+    DESIGN.md calls `fft_period` part of the pair mode's definition."""
+    from scipy import signal
+    rng = np.random.default_rng(17)
+    up, big = 4, 512
+    for (ny, nx), noise in (((70, 66), 0.0), ((85, 85), 0.02), ((100, 90), 0.0), ((128, 128), 0.02), ((97, 128), 0.0)):
+        tx, ty = rng.uniform(-2.5, 2.5, 2)
+        ref, img = datagen.pair_set(ny, nx, tx, ty, rng.uniform(4, 6), 1.3, np.float64,
+                                    noise_seed=5 if noise else 0, noise_level=noise)
+        assert orc.fft_period(ny, nx) == (128 if max(ny, nx) <= 85 else 192)
+        exp = np.array(orc.xcorr_refine(ref, img, up))
+        # c[l] = sum ref[x] img[x - l], lags -(n-1)..(n-1), by direct summation
+        full = signal.correlate(ref, img, mode='full', method='direct')
+        grid = np.zeros((big, big))
+        ly = np.arange(-(ny - 1), ny) % big
+        lx = np.arange(-(nx - 1), nx) % big
+        grid[np.ix_(ly, lx)] = full
+        spec = np.fft.fft2(grid)
+        spec = orc._pad_spectrum_1d(spec, big, up, 0)
+        spec = orc._pad_spectrum_1d(spec, big, up, 1)
+        fine = np.fft.ifft2(spec).real * (up * up)
+        iy = (up * (ny - 1 - ny // 2) - np.arange(up * ny)) % (big * up)
+        ix = (up * (nx - 1 - nx // 2) - np.arange(up * nx)) % (big * up)
+        xm, ym = orc.find_peak(fine[np.ix_(iy, ix)], peak_fit_box=5, peak_search_box='all')
+        got = np.array([xm / up - (nx - 1) // 2, ym / up - (ny - 1) // 2])
+        err = np.max(np.abs(got - exp))
+        assert err < (3e-3 if noise else 1e-8), ((ny, nx), noise, err)
+        if not noise:
+            assert np.max(np.abs(got - np.array([tx, ty]))) < 2e-3
