@@ -70,7 +70,7 @@
 extern "C" {
 #endif
 
-#define SPX_ABI_VERSION 2
+#define SPX_ABI_VERSION 3
 
 /* cc_type (cc.py:107-111; anything else than NCC/ZNCC means plain CC) */
 #define SPX_CC 0
@@ -263,6 +263,47 @@ int spx_blot_affine4_f32(const float* src, int64_t nbatch, int sny, int snx, con
  */
 int spx_blot_poly4_f32(const float* src, int64_t nbatch, int sny, int snx, const double* coef,
                        int degree, const float* gain, int ny, int nx, float* im4, void* stream);
+
+/*
+ * Catalog-scale entries (round 3): the body of the loop align.py:656-699 for a whole catalog whose cutouts
+ * all have DIFFERENT shapes (bounding box + padding per source, cutout.py:159-175), without a host loop
+ * over sources or pixels.  Packed layout shared by the three calls: item p's (h x w) pixels, row-major, at
+ * element item_offset[p] of a flat float32 buffer; its four dithered blots at 4 * item_offset[p]
+ * (order 00, 10, 01, 11); its interlaced image (2h x 2w) at 4 * item_offset[p] of `out_icc`;
+ * item_shape = int32 [nbatch][2] = (h, w).
+ */
+
+/* frame -> packed cutouts (cutout.py:689-797 slicing/fill + align.py:661 zeroing; see spx_gather_cutouts_f32
+ * for `fill`, `fmask`, `seg`, `ids`): boxes int32 [nbatch][4] = (x0, y0, w, h). */
+int spx_gather_cutouts_var_f32(const float* frame, const uint8_t* fmask, int fny, int fnx,
+                               const int32_t* boxes, int64_t nbatch, const int64_t* item_offset,
+                               float fill, float* packed, const int32_t* seg, const int32_t* ids,
+                               void* stream);
+
+/* packed drizzled cutouts -> packed blots (the four blot_cutout calls of align.py:664-676 per source).
+ *   map    : degree == 0: float64 [nbatch][6] affine maps as spx_blot_affine4_f32;
+ *            degree 1..5: float64 [nbatch][2][21] polynomial maps as spx_blot_poly4_f32
+ *   src_*  : layout of the drizzled cutouts, dst_* : layout of the image cutouts the blots are made for
+ *            (sources smaller than 6 px per side give all-zero blots) */
+int spx_blot4_var_f32(const float* src, const int64_t* src_offset, const int32_t* src_shape,
+                      int64_t nbatch, const double* map, int degree, const float* gain,
+                      const int64_t* dst_offset, const int32_t* dst_shape, float* im4, void* stream);
+
+/* cc.find_displacement for every item of a packed catalog: ONE call launches each kernel family named in
+ * `family_mask` (bit 0: larger side 3..32 px, bit 1: 33..64, bit 2: 65..85, bit 3: 86..128) over the same
+ * tables; each family takes its own items and leaves the others alone.  Items no launched family takes
+ * (a side below 3 or above 128 px, or a family whose bit is not set) are NOT written: pre-fill out_dxdy /
+ * out_status with your "not measured" values.  workspace: spx_workspace_bytes_xcorr(nbatch, 128, 128)
+ * bytes when bit 3 is set, else none.  out_icc must be given. */
+#define SPX_FAMILY_32 1
+#define SPX_FAMILY_64 2
+#define SPX_FAMILY_85 4
+#define SPX_FAMILY_128 8
+int spx_find_displacement5_catalog_f32(const float* ref, const float* im4, const int64_t* item_offset,
+                                       const int32_t* item_shape, int64_t nbatch, int family_mask,
+                                       int cc_type, double* out_dxdy, int32_t* out_status,
+                                       float* out_icc, void* workspace, size_t workspace_bytes,
+                                       void* stream);
 
 /*
  * Synthetic Gaussian-spot pairs: pair k = first_index + i has

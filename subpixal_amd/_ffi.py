@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SPX_HIP_LIB: another build of the same library (A/B measurements only: tools/gpu_r3_variants.sh)
 LIB_PATH = os.environ.get('SPX_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libsubpixal_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_SIDE = 682
 MAX_UPSAMPLE = 59
 
@@ -42,6 +42,11 @@ _SIGNATURES = {
                                                   _vp, _vp, _c.c_size_t, _vp]),
     'spx_find_displacement5_var_f64': (_c.c_int, [_vp, _vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _vp, _vp,
                                                   _vp, _vp, _c.c_size_t, _vp]),
+    'spx_find_displacement5_catalog_f32': (_c.c_int, [_vp, _vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _vp, _vp,
+                                                      _vp, _vp, _c.c_size_t, _vp]),
+    'spx_gather_cutouts_var_f32': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _vp, _c.c_int64, _vp, _c.c_float,
+                                              _vp, _vp, _vp, _vp]),
+    'spx_blot4_var_f32': (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _vp, _c.c_int, _vp, _vp, _vp, _vp, _vp]),
     'spx_find_peak_f64': (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                      _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _vp]),
     'spx_gather_cutouts_f32': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _vp, _c.c_int64,

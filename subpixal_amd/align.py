@@ -46,13 +46,14 @@ def _shape_ok(shape):
 # robust linear fit of matched point lists (host, float64)
 # ----------------------------------------------------------------------------
 def _weighted_fit(xy, uv, w, fitgeom):
-    """Fit uv ~ F @ xy + t (xy already centred).  Returns (F 2x2, t 2)."""
+    """Fit uv ~ F @ xy + t (xy already centred) with weights ``w`` (zero = point not used; no copies of the
+    point lists are made, so a clipping round costs a few passes over the arrays).  Returns (F 2x2, t 2)."""
     sw = np.sum(w)
     if fitgeom == 'shift':
-        t = np.sum(w[:, None] * (uv - xy), axis=0) / sw
+        t = w @ (uv - xy) / sw
         return np.eye(2), t
-    mx = np.sum(w[:, None] * xy, axis=0) / sw
-    mu = np.sum(w[:, None] * uv, axis=0) / sw
+    mx = w @ xy / sw
+    mu = w @ uv / sw
     x = xy - mx
     u = uv - mu
     if fitgeom == 'rscale':
@@ -62,9 +63,10 @@ def _weighted_fit(xy, uv, w, fitgeom):
         b = np.sum(w * (x[:, 0] * u[:, 1] - x[:, 1] * u[:, 0])) / sxx
         f = np.array([[a, -b], [b, a]])
     elif fitgeom == 'general':
-        # affine: two independent weighted least squares sharing the design matrix
-        sq = np.sqrt(w)[:, None]
-        f = np.linalg.lstsq(sq * x, sq * u, rcond=None)[0].T
+        # affine: normal equations on the centred coordinates (a 2x2 system whose condition number is the
+        # aspect ratio of the point cloud): F = (sum w u x^T) (sum w x x^T)^-1
+        xw = x * w[:, None]
+        f = np.linalg.solve(xw.T @ x, xw.T @ u).T
     else:
         raise ValueError("Unsupported 'fitgeom'. Valid values are: 'shift', 'rscale', 'general'.")
     t = mu - f @ mx
@@ -97,21 +99,23 @@ def iter_linear_fit(xy, uv, wxy=None, wuv=None, fitgeom='general', center=None, 
     if mask.sum() < minpts:
         raise ValueError("Not enough points with non-zero weight for the requested fit geometry.")
     eff = 0
+    xc, uc = xy - c, uv - c
     for it in range(max(0, int(nclip)) + 1):
-        f, t = _weighted_fit(xy[mask] - c, uv[mask] - c, w[mask], fitgeom)
-        resid = (uv - c) - ((xy - c) @ f.T + t)
+        wm = w * mask
+        f, t = _weighted_fit(xc, uc, wm, fitgeom)
+        resid = uc - (xc @ f.T + t)
         if it == nclip or sigma is None:
             break
-        r2 = np.sum(resid ** 2, axis=1)
-        sw = np.sum(w[mask])
-        rms = np.sqrt(np.sum(w[mask] * r2[mask]) / sw)
-        keep = mask & (np.sqrt(r2) <= sigma * rms)
-        if keep.sum() == mask.sum() or keep.sum() < minpts:
+        r2 = resid[:, 0] ** 2 + resid[:, 1] ** 2
+        rms = np.sqrt((wm @ r2) / np.sum(wm))
+        keep = mask & (r2 <= (sigma * rms) ** 2)
+        nkeep = np.count_nonzero(keep)
+        if nkeep == np.count_nonzero(mask) or nkeep < minpts:
             break
         mask = keep
         eff += 1
-    sw = np.sum(w[mask])
-    rms = np.sqrt(np.sum(w[mask, None] * resid[mask] ** 2, axis=0) / sw)
+    wm = w * mask
+    rms = np.sqrt((wm @ resid ** 2) / np.sum(wm))
     rotx = np.degrees(np.arctan2(f[1, 0], f[0, 0]))
     roty = np.degrees(np.arctan2(-f[0, 1], f[1, 1]))
     sx = float(np.hypot(f[0, 0], f[1, 0]))
@@ -197,6 +201,107 @@ def measure_shifts_affine(img_tiles, drz_tiles, affine, gain=None, cc_type='NCC'
     return dxdy, iccs, blt00, status
 
 
+def _fit_from_shifts(img_dxy, status, xyim, xyref, weights, wcslin, fitgeom, nclip, sigma):
+    """The tail of align.py:701-745 shared by the list and the catalog path: zero weight for sources
+    without a measurement, the robust fit, ``irmse``."""
+    npts = len(img_dxy)
+    good = usable_status(status)
+    ref_dxy = xyim - xyref
+    user_weights = weights is not None
+    if not np.all(good):
+        weights = (np.ones(npts) if weights is None else weights) * good
+    center = None
+    if wcslin is not None and hasattr(wcslin, 'wcs'):
+        center = np.array(wcslin.wcs.crpix)
+    fit = iter_linear_fit(xyim, xyref, wxy=None, wuv=weights, fitgeom=fitgeom, center=center,
+                          nclip=nclip, sigma=sigma)
+    fit['subpixal_img_dxy'] = img_dxy
+    fit['subpixal_ref_dxy'] = ref_dxy
+    fit['subpixal_status'] = status
+    m = fit['fitmask']
+    if not user_weights:                                                   # align.py:730-743
+        fit['irmse'] = float(np.sqrt(2 * np.mean(img_dxy[m] ** 2)))
+    else:
+        wt = np.sum(weights)
+        if len(weights) == 0 or wt == 0.0:
+            fit['irmse'] = float('nan')
+        else:
+            w = weights / wt
+            fit['irmse'] = float(np.sqrt(np.sum(np.dot(w[m], img_dxy[m] ** 2))))
+    return fit
+
+
+def _find_linear_fit_catalog(img_cat, drz_cat, wcslin, fitgeom, nclip, sigma, use_weights, cc_type, blot,
+                             affine, gain, poly):
+    """``find_linear_fit`` for two :class:`~subpixal_amd.cutout.CutoutCatalog` (the image's and the drizzled
+    image's cutouts of the same sources): the loop body of align.py:656-699 runs on the device for the whole
+    catalog -- gather of the variable-shape cutouts from the resident frames, masked pixels of the drizzled
+    cutouts zeroed (align.py:661), the four blots per source, ``cc.find_displacement`` -- with no host loop
+    over sources; only the (dx, dy) and status arrays come back for the fit.  Per source the arithmetic is that
+    of the list path, so the shifts are bit-identical to calling ``cc.find_displacement`` source by source."""
+    import torch
+    from . import blot as _blot
+    from .cutout import CutoutCatalog, PackedImages
+    if not (isinstance(img_cat, CutoutCatalog) and isinstance(drz_cat, CutoutCatalog)):
+        raise ValueError("img_cutouts and drz_cutouts must both be CutoutCatalog objects (or neither).")
+    if len(img_cat) != len(drz_cat):                                       # align.py:631-633
+        raise ValueError("The number of image cutouts must match the number "
+                         "of drizzled cutouts.")
+    if blot is not None or (affine is None) == (poly is None):
+        raise ValueError("The catalog path takes the target->source maps as 'affine' or 'poly' (blot.map_from), "
+                         "not a 'blot' callable.")
+    npts = len(img_cat)
+    degree = 0
+    maps = affine
+    if poly is not None:
+        maps, degree = poly
+    if wcslin is None and drz_cat.wcs is not None:
+        wcslin = drz_cat.wcs                                               # align.py:636-639
+    if wcslin is not None and hasattr(wcslin, 'deepcopy'):
+        wcslin = wcslin.deepcopy()
+
+    img_p, img_off, img_shp = img_cat.packed(zero_masked=False)
+    drz_p, drz_off, drz_shp = drz_cat.packed(zero_masked=True)             # align.py:661
+    shapes = img_cat.shapes
+    total = int((shapes[:, 0].astype(np.int64) * shapes[:, 1]).sum())
+    im4 = _blot.blot4_packed(drz_p, drz_off, drz_shp, maps, img_off, img_shp, total, degree, gain)
+    d, st, icc = cc.find_displacement_packed(img_p, im4, img_off, img_shp, shapes, cc_type=cc_type)
+    offs_host = np.zeros(npts, dtype=np.int64)
+    if npts > 1:
+        np.cumsum((shapes[:-1, 0].astype(np.int64) * shapes[:-1, 1]), out=offs_host[1:])
+    # cutouts above 128 px (general path): one launch per shape, from the packed buffers (rare)
+    side, low = shapes.max(axis=1), shapes.min(axis=1)
+    for shp in {tuple(x) for x in shapes[(side > 128) & (side <= _ffi.MAX_SIDE) & (low >= 3)]}:
+        idx = np.nonzero((shapes == np.array(shp)).all(axis=1))[0]
+        npx = shp[0] * shp[1]
+        ref = torch.stack([img_p[o:o + npx].view(*shp) for o in offs_host[idx]])
+        b4 = torch.stack([im4[4 * o:4 * o + 4 * npx].view(4, *shp) for o in offs_host[idx]])
+        db, ib, sb = cc.find_displacement_batch(ref, b4, cc_type=cc_type, full_output=True, return_status=True)
+        it = torch.from_numpy(idx).to(d.device)
+        d[it], st[it] = db, sb
+        for j, o in enumerate(offs_host[idx]):
+            icc[4 * o:4 * o + 4 * npx] = ib[j].reshape(-1)
+    img_dxy = d.cpu().numpy()
+    status = st.cpu().numpy()
+    img_dxy = np.where(status[:, None] == ST_SKIPPED, 0.0, img_dxy)        # not measured: shift 0, zero weight
+
+    def frame_xy(x, y):
+        # align.py:692-699 for every source at once; without WCS objects: 1-based pixel coordinates of the
+        # parent image (the list path's `_image_xy`)
+        if wcslin is not None and img_cat.wcs is not None:
+            ra, dec = img_cat.wcs.all_pix2world(x, y, 0)
+            return np.stack(wcslin.wcs_world2pix(ra, dec, 1), axis=1).astype(np.float64)
+        return np.stack([x + 1.0, y + 1.0], axis=1)
+
+    xyim = frame_xy(img_cat.src_pos[:, 0], img_cat.src_pos[:, 1])
+    xyref = frame_xy(img_cat.src_pos[:, 0] + img_dxy[:, 0], img_cat.src_pos[:, 1] + img_dxy[:, 1])
+    weights = drz_cat.src_weight if use_weights else None                  # align.py:703-716
+    fit = _fit_from_shifts(img_dxy, status, xyim, xyref, weights, wcslin, fitgeom, nclip, sigma)
+    interlaced_cc = PackedImages(icc, offs_host, 2 * shapes, scale=4)
+    nonshifted_blts = PackedImages(im4, offs_host, shapes, scale=4, part=0)
+    return fit, interlaced_cc, nonshifted_blts
+
+
 def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
                     nclip=3, sigma=3.0, use_weights=True, cc_type='NCC', blot=None,
                     affine=None, gain=None, poly=None):
@@ -215,6 +320,10 @@ def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
     poly : ``(coef [N, 2, 21], degree)`` polynomial maps (``blot.poly_from_map`` / ``blot.map_from``) for
         cutouts over which instrument distortion makes the map non-affine; used like ``affine``.
     """
+    from .cutout import CutoutCatalog
+    if isinstance(img_cutouts, CutoutCatalog) or isinstance(drz_cutouts, CutoutCatalog):
+        return _find_linear_fit_catalog(img_cutouts, drz_cutouts, wcslin, fitgeom, nclip, sigma, use_weights,
+                                        cc_type, blot, affine, gain, poly)
     if not hasattr(img_cutouts, '__iter__'):
         img_cutouts = [img_cutouts]
     if not hasattr(drz_cutouts, '__iter__') or (blot is not None and hasattr(drz_cutouts, 'data')):
@@ -273,11 +382,6 @@ def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
             [[data_of(b) for b in four] for four in blts], cc_type=cc_type, full_output=True,
             return_status=True)
         nonshifted_blts = [four[0] for four in blts]
-    # Sources without a measurement (non-finite pixels, e.g. the NaN fill of a cutout overhanging
-    # its frame; an oversized cutout) get zero weight instead of poisoning the fit with a
-    # meaningless shift.  The reference has no such guard: it would fit whatever came back.
-    good = usable_status(status)
-
     xyim = np.empty((npts, 2))
     xyref = np.empty((npts, 2))
     for k, imct in enumerate(img_cutouts):
@@ -289,7 +393,6 @@ def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
             ny, nx = np.shape(data_of(imct))
             xyim[k] = ((nx - 1) / 2.0, (ny - 1) / 2.0)
             xyref[k] = xyim[k] + img_dxy[k]
-    ref_dxy = xyim - xyref
 
     weights = None
     if use_weights:                                                        # align.py:703-716
@@ -305,26 +408,8 @@ def find_linear_fit(img_cutouts, drz_cutouts, wcslin=None, fitgeom='general',
             raise ValueError("Weights must be non-negative.")
         else:
             weights = np.asarray(weights, dtype=np.float64)
-    user_weights = weights is not None
-    if not np.all(good):
-        weights = (np.ones(npts) if weights is None else weights) * good
-
-    center = None
-    if wcslin is not None and hasattr(wcslin, 'wcs'):
-        center = np.array(wcslin.wcs.crpix)
-    fit = iter_linear_fit(xyim, xyref, wxy=None, wuv=weights, fitgeom=fitgeom, center=center,
-                          nclip=nclip, sigma=sigma)
-    fit['subpixal_img_dxy'] = img_dxy
-    fit['subpixal_ref_dxy'] = ref_dxy
-    fit['subpixal_status'] = status
-    m = fit['fitmask']
-    if not user_weights:                                                   # align.py:730-743
-        fit['irmse'] = float(np.sqrt(2 * np.mean(img_dxy[m] ** 2)))
-    else:
-        wt = np.sum(weights)
-        if len(weights) == 0 or wt == 0.0:
-            fit['irmse'] = float('nan')
-        else:
-            w = weights / wt
-            fit['irmse'] = float(np.sqrt(np.sum(np.dot(w[m], img_dxy[m] ** 2))))
+    # Sources without a measurement (non-finite pixels, e.g. the NaN fill of a cutout overhanging
+    # its frame; an oversized cutout) get zero weight instead of poisoning the fit with a
+    # meaningless shift.  The reference has no such guard: it would fit whatever came back.
+    fit = _fit_from_shifts(img_dxy, status, xyim, xyref, weights, wcslin, fitgeom, nclip, sigma)
     return fit, interlaced_cc, nonshifted_blts

@@ -19,7 +19,7 @@ import torch
 
 from . import _ffi, device
 
-__all__ = ['blot_affine4_batch', 'blot_poly4_batch', 'affine_from_map', 'poly_from_map', 'map_from',
+__all__ = ['blot_affine4_batch', 'blot_poly4_batch', 'blot4_packed', 'affine_from_map', 'poly_from_map', 'map_from',
            'shift_affine', 'POLY_TERMS']
 
 POLY_TERMS = 21          # monomials u^i v^j with i + j <= 5
@@ -184,3 +184,32 @@ def blot_affine4_batch(src, affine, shape, gain=None):
                                             device.ptr(a), device.ptr(g), ny, nx, device.ptr(im4),
                                             device.stream_ptr()))
     return im4 if like_torch else im4.cpu().numpy()
+
+
+def blot4_packed(src, src_offsets, src_shapes, maps, dst_offsets, dst_shapes, dst_total, degree=0, gain=None):
+    """The four dithered blots of every source of a packed catalog (``spx_blot4_var_f32``): ``src`` holds the
+    drizzled cutouts back to back (``cutout.pack_cutouts_var`` layout: ``src_offsets`` int64 [N],
+    ``src_shapes`` int32 [N, 2] = (h, w)), the blots are made for image cutouts laid out by ``dst_offsets`` /
+    ``dst_shapes`` (``dst_total`` pixels in all).  ``maps``: ``[N, 6]`` affines (``degree`` 0) or ``[N, 2, 21]``
+    polynomial coefficients (``degree`` 1..5).  Returns the flat float32 device buffer
+    ``[item][4][pixels]`` (item k at ``4 * dst_offsets[k]``)."""
+    n = int(src_offsets.shape[0])
+    degree = int(degree)
+    m = np.asarray(maps, dtype=np.float64) if not isinstance(maps, torch.Tensor) else maps
+    want = (n, 6) if degree == 0 else (n, 2, POLY_TERMS)
+    if tuple(m.shape) != want:
+        raise ValueError("maps must have shape %s." % (want,))
+    m = device.to_device(m, torch.float64)
+    g = None
+    if gain is not None:
+        g = device.to_device(np.asarray(gain, dtype=np.float32) if not isinstance(gain, torch.Tensor)
+                             else gain, torch.float32)
+        if g.dim() != 1 or g.shape[0] != n:
+            raise ValueError("gain must have shape [N].")
+    im4 = torch.empty((max(4 * int(dst_total), 1),), dtype=torch.float32, device=src.device)
+    lib = _ffi.load()
+    with torch.cuda.device(src.device):
+        _ffi.check(lib.spx_blot4_var_f32(device.ptr(src), device.ptr(src_offsets), device.ptr(src_shapes), n,
+                                         device.ptr(m), degree, device.ptr(g), device.ptr(dst_offsets),
+                                         device.ptr(dst_shapes), device.ptr(im4), device.stream_ptr()))
+    return im4

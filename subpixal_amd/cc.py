@@ -11,7 +11,8 @@ import torch
 
 from . import _ffi, device
 
-__all__ = ['find_displacement', 'find_displacement_batch', 'find_displacement_var', 'xcorr_refine_batch']
+__all__ = ['find_displacement', 'find_displacement_batch', 'find_displacement_var', 'find_displacement_packed',
+           'xcorr_refine_batch']
 
 
 def _cc_code(cc_type):
@@ -188,6 +189,37 @@ def find_displacement_var(refs, im4s, cc_type='NCC', full_output=False, return_s
     if return_status:
         res.append(status)
     return res[0] if len(res) == 1 else tuple(res)
+
+
+def find_displacement_packed(ref, im4, offsets, shapes, shapes_host, cc_type='NCC'):
+    """``find_displacement`` for a whole catalog already packed on the device
+    (``spx_find_displacement5_catalog_f32``): ``ref`` float32 [total] holds the reference cutouts back to
+    back (item k = ``shapes[k] = (h, w)`` pixels at ``offsets[k]``), ``im4`` float32 [4 total] their four
+    blots at ``4 offsets[k]``; ``offsets`` / ``shapes`` are CUDA tensors, ``shapes_host`` the same shapes as a
+    numpy array (it only steers which kernel families are launched: no device round trip).
+
+    Returns CUDA tensors ``(dxdy [N, 2] float64, status [N] int32, icc float32 [4 total])``; items no kernel
+    family takes (a side below 3 or above 128 px) keep ``(nan, nan)`` / status -1."""
+    n = int(offsets.shape[0])
+    dev = ref.device
+    out = torch.full((n, 2), float('nan'), dtype=torch.float64, device=dev)
+    status = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    icc = torch.empty((max(int(im4.shape[0]), 1),), dtype=torch.float32, device=dev)
+    side = np.asarray(shapes_host).max(axis=1) if n else np.zeros(0, int)
+    low = np.asarray(shapes_host).min(axis=1) if n else np.zeros(0, int)
+    ok = low >= 3
+    mask = 0
+    for bit, lo, hi in ((1, 2, 32), (2, 32, 64), (4, 64, 85), (8, 85, 128)):
+        if np.any(ok & (side > lo) & (side <= hi)):
+            mask |= bit
+    lib = _ffi.load()
+    with torch.cuda.device(dev):
+        ws, ws_bytes = _workspace(lib.spx_workspace_bytes_xcorr(n, 128, 128) if mask & 8 else 0, dev)
+        _ffi.check(lib.spx_find_displacement5_catalog_f32(
+            device.ptr(ref), device.ptr(im4), device.ptr(offsets), device.ptr(shapes), n, mask,
+            _cc_code(cc_type), device.ptr(out), device.ptr(status), device.ptr(icc), device.ptr(ws), ws_bytes,
+            device.stream_ptr()))
+    return out, status, icc
 
 
 def find_displacement(ref_image, image00, image10, image01, image11,

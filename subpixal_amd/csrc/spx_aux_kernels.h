@@ -229,6 +229,79 @@ void blot_poly4_kernel(const float* __restrict__ src, int64_t nbatch, int sny, i
 }
 
 // ---------------------------------------------------------------------------
+// Catalog-scale packing (round 3): the same two operations for cutouts of DIFFERENT shapes -- the reference's
+// cutouts are bounding boxes + padding, one shape per source (cutout.py:159-175) -- writing the packed
+// layouts the variable-shape reference-mode kernels read (spx_kernels.h ItemTable): item p's pixels at
+// element off[p] of the output, row-major (h x w), its four blots at 4 off[p].  One workgroup per item
+// (grid-stride), so a 5000-source catalog is one launch and no host loop touches a pixel.
+// ---------------------------------------------------------------------------
+SPX_TKERNEL(256)
+void gather_cutouts_var_kernel(const float* __restrict__ frame, const uint8_t* __restrict__ fmask,
+                               int fny, int fnx, const int32_t* __restrict__ boxes, int64_t nbatch,
+                               const int64_t* __restrict__ off, float fill, float* __restrict__ out,
+                               const int32_t* __restrict__ seg, const int32_t* __restrict__ ids) {
+    for (int64_t b = rt::block_id(); b < nbatch; b += rt::grid_size()) {
+        const int x0 = boxes[4 * b], y0 = boxes[4 * b + 1];
+        const int w = boxes[4 * b + 2], h = boxes[4 * b + 3];
+        float* dst = out + off[b];
+        const int npx = w * h;
+        for (int i = rt::thread_id(); i < npx; i += 256) {
+            const int ty = i / w, tx = i - ty * w;
+            const int fx = x0 + tx, fy = y0 + ty;
+            float v = fill;
+            if (fx >= 0 && fx < fnx && fy >= 0 && fy < fny) {
+                const float f = frame[(int64_t)fy * fnx + fx];
+                const bool bad = (fmask && fmask[(int64_t)fy * fnx + fx]) || !(f - f == 0.0f) ||
+                                 (seg && seg[(int64_t)fy * fnx + fx] != ids[b]);
+                if (!bad) v = f;
+            }
+            dst[i] = v;
+        }
+    }
+}
+
+// the four dithered blots of every source from its own (variable-shape) drizzled cutout: `map` holds 6
+// doubles per source (degree 0: affine, as blot_affine4_kernel) or 2 x 21 (degree 1..5: polynomial, as
+// blot_poly4_kernel); the same arithmetic per output pixel as those kernels
+SPX_TKERNEL(256)
+void blot4_var_kernel(const float* __restrict__ src, const int64_t* __restrict__ src_off,
+                      const int32_t* __restrict__ src_shp, int64_t nbatch, const double* __restrict__ map,
+                      int degree, const float* __restrict__ gain, const int64_t* __restrict__ dst_off,
+                      const int32_t* __restrict__ dst_shp, float* __restrict__ im4) {
+    for (int64_t b = rt::block_id(); b < nbatch; b += rt::grid_size()) {
+        const int sny = src_shp[2 * b], snx = src_shp[2 * b + 1];
+        const int ny = dst_shp[2 * b], nx = dst_shp[2 * b + 1];
+        const float* tile = src + src_off[b];
+        float* dst = im4 + 4 * dst_off[b];
+        const int npx = ny * nx;
+        const float g = gain ? gain[b] : 1.0f;
+        if (sny < 6 || snx < 6) {            // (the fixed-shape entry refuses such sources; here: no signal)
+            for (int i = rt::thread_id(); i < 4 * npx; i += 256) dst[i] = 0.0f;
+            continue;
+        }
+        const double xc = 0.5 * (double)(nx - 1), yc = 0.5 * (double)(ny - 1);
+        for (int r = rt::thread_id(); r < 4 * npx; r += 256) {
+            const int q = r / npx;                       // 0: 00, 1: 10, 2: 01, 3: 11
+            const int y = (r - q * npx) / nx, x = r % nx;
+            const double xt = (double)x + ((q & 1) ? 0.5 : 0.0), yt = (double)y + ((q & 2) ? 0.5 : 0.0);
+            double xs, ys;
+            if (degree == 0) {
+                const double* a = map + 6 * b;
+                xs = a[0] * xt + a[1] * yt + a[2];
+                ys = a[3] * xt + a[4] * yt + a[5];
+            } else {
+                const double* c = map + (int64_t)b * 2 * kBlotPolyTerms;
+                xs = blot_poly_eval(c, degree, xt - xc, yt - yc);
+                ys = blot_poly_eval(c + kBlotPolyTerms, degree, xt - xc, yt - yc);
+            }
+            float v = blot_resample(tile, sny, snx, xs, ys);
+            if (gain) v *= g;
+            dst[r] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Bounding boxes of all segments of a label image in ONE pass (the reference scans the
 // whole frame once per source: `segmentation_image == sid` + np.where, cutout.py:151-160,
 // O(N_src * N_pix)).  boxes[l] = (xmin, ymin, xmax, ymax), counts[l] = pixels, for labels

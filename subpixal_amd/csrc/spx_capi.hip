@@ -461,7 +461,7 @@ int find_displacement5(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, i
     int rc = current_tables(&t);
     if (rc) return rc;
     Disp5Args a;
-    a.items = spx::ItemTable{nullptr, nullptr, 0};
+    a.items = spx::ItemTable{nullptr, nullptr, 0, 0};
     a.nbatch = nbatch; a.ny = ny; a.nx = nx; a.cc_type = cc_type;
     a.icc = out_icc ? out_icc : reinterpret_cast<float*>(wsb + tile_ws);
     a.out = out_dxdy; a.status = out_status;
@@ -504,7 +504,7 @@ int find_displacement5_var(const TIn* ref, const TIn* im4, const int64_t* item_o
     Disp5Args a;
     // the largest side the family launched here takes: 32 / 64 / 85 (fold path) / 128
     a.items = spx::ItemTable{item_offset, item_shape,
-                             tile == TILE32 ? 32 : (tile == TILE64 ? (fold ? kFoldMaxSide : 64) : 128)};
+                             tile == TILE32 ? 32 : (tile == TILE64 ? (fold ? kFoldMaxSide : 64) : 128), 0};
     a.nbatch = nbatch; a.ny = family_side; a.nx = family_side; a.cc_type = cc_type;
     a.icc = out_icc;
     a.out = out_dxdy; a.status = out_status;
@@ -725,6 +725,74 @@ int spx_find_displacement5_var_f64(const double* ref, const double* im4, const i
                                    void* workspace, size_t workspace_bytes, void* stream) {
     return find_displacement5_var<double>(ref, im4, item_offset, item_shape, nbatch, family_side, cc_type,
                                           out_dxdy, out_status, out_icc, workspace, workspace_bytes, stream);
+}
+
+int spx_find_displacement5_catalog_f32(const float* ref, const float* im4, const int64_t* item_offset,
+                                       const int32_t* item_shape, int64_t nbatch, int family_mask,
+                                       int cc_type, double* out_dxdy, int32_t* out_status,
+                                       float* out_icc, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    if (nbatch < 0 || (nbatch > 0 && (!ref || !im4 || !item_offset || !item_shape || !out_dxdy || !out_icc)))
+        return fail(SPX_E_ARG, "null pointer or negative batch");
+    if (family_mask & ~15) return fail(SPX_E_ARG, "family_mask has bits 0..3");
+    if (nbatch == 0 || family_mask == 0) return 0;
+    const size_t need = (family_mask & SPX_FAMILY_128) ? ws_bytes_xcorr(nbatch, 128, 128) : 0;
+    if (need > 0 && (!workspace || workspace_bytes < need))
+        return fail(SPX_E_WORKSPACE, "workspace missing or smaller than spx_workspace_bytes_xcorr(nbatch, 128, 128)");
+    DeviceTables* t = nullptr;
+    int rc = current_tables(&t);
+    if (rc) return rc;
+    // (largest side taken, sides at or below this are another family's, tile, fold path)
+    static const struct { int bit, max_side, skip_below; Tile tile; bool fold; } fam[4] = {
+        {SPX_FAMILY_32, 32, 2, TILE32, false}, {SPX_FAMILY_64, 64, 32, TILE64, false},
+        {SPX_FAMILY_85, kFoldMaxSide, 64, TILE64, true}, {SPX_FAMILY_128, 128, kFoldMaxSide, TILE192, false}};
+    TableLock lk;
+    if (!t->ready) return fail(SPX_E_ARG, "spx_shutdown() ran between the call's start and its launch");
+    lk.enter_launch(t);
+    for (int k = 0; k < 4; ++k) {
+        if (!(family_mask & fam[k].bit)) continue;
+        Disp5Args a;
+        a.items = spx::ItemTable{item_offset, item_shape, fam[k].max_side, fam[k].skip_below};
+        a.nbatch = nbatch; a.ny = fam[k].max_side; a.nx = fam[k].max_side; a.cc_type = cc_type;
+        a.icc = out_icc;
+        a.out = out_dxdy; a.status = out_status;
+        a.ws = reinterpret_cast<float*>(workspace);
+        a.s = reinterpret_cast<hipStream_t>(stream);
+        if ((rc = run_disp5<float>(t, fam[k].tile, fam[k].fold, ref, im4, a, true))) return rc;
+    }
+    return 0;
+}
+
+int spx_gather_cutouts_var_f32(const float* frame, const uint8_t* fmask, int fny, int fnx,
+                               const int32_t* boxes, int64_t nbatch, const int64_t* item_offset,
+                               float fill, float* packed, const int32_t* seg, const int32_t* ids,
+                               void* stream) {
+    if (nbatch < 0 || (nbatch > 0 && (!frame || !boxes || !item_offset || !packed)))
+        return fail(SPX_E_ARG, "null pointer or negative batch");
+    if ((seg == nullptr) != (ids == nullptr))
+        return fail(SPX_E_ARG, "seg and ids must be given together");
+    if (fny < 1 || fnx < 1) return fail(SPX_E_SHAPE, "bad shape");
+    if (nbatch == 0) return 0;
+    const unsigned grid = (unsigned)(nbatch < 65535 * 16 ? nbatch : 65535 * 16);
+    hipLaunchKernelGGL(spx::gather_cutouts_var_kernel, dim3(grid), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), frame, fmask, fny, fnx, boxes, nbatch,
+                       item_offset, fill, packed, seg, ids);
+    SPX_HIP(hipGetLastError());
+    return 0;
+}
+
+int spx_blot4_var_f32(const float* src, const int64_t* src_offset, const int32_t* src_shape,
+                      int64_t nbatch, const double* map, int degree, const float* gain,
+                      const int64_t* dst_offset, const int32_t* dst_shape, float* im4, void* stream) {
+    if (nbatch < 0 || (nbatch > 0 && (!src || !src_offset || !src_shape || !map || !dst_offset || !dst_shape || !im4)))
+        return fail(SPX_E_ARG, "null pointer or negative batch");
+    if (degree < 0 || degree > 5) return fail(SPX_E_ARG, "degree: 0 (affine) or 1..5 (polynomial)");
+    if (nbatch == 0) return 0;
+    const unsigned grid = (unsigned)(nbatch < 65535 * 16 ? nbatch : 65535 * 16);
+    hipLaunchKernelGGL(spx::blot4_var_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       src, src_offset, src_shape, nbatch, map, degree, gain, dst_offset, dst_shape, im4);
+    SPX_HIP(hipGetLastError());
+    return 0;
 }
 
 int spx_find_peak_f64(const double* image, const uint8_t* mask, const double* guess,

@@ -1638,23 +1638,34 @@ SPX_DEVICE void disp5_body(const TIn* __restrict__ ref, const TIn* __restrict__ 
 // shp[2p] x shp[2p+1] = (ny, nx) pixels, its interlaced image at 4 off[p] of `icc`.  Null tables:
 // a uniform batch of (ny, nx) cutouts.  An item whose shape the kernel family launched for it cannot
 // take (side below 3 or above `max_side`) is not computed: (NaN, NaN), status ST_SHAPE.
+// Catalog mode (`skip_below` > 0, round 3): several kernel families are launched over the SAME table, each
+// taking the items whose larger side lies in (skip_below, max_side] and passing over the others without
+// writing anything (the caller pre-fills the results with "not measured").
 struct ItemTable {
     const int64_t* off;
     const int* shp;
     int max_side;
+    int skip_below;
 };
 struct ItemView {
     int64_t off;
     int ny, nx;
     bool ok;
+    bool skip;       // not this launch's item: leave its results alone
 };
 SPX_DEVICE ItemView item_view(const ItemTable& t, int64_t p, int ny, int nx) {
     ItemView v;
+    v.skip = false;
     if (t.off) {
         v.off = t.off[p];
         v.ny = t.shp[2 * p];
         v.nx = t.shp[2 * p + 1];
         v.ok = v.ny >= 3 && v.nx >= 3 && v.ny <= t.max_side && v.nx <= t.max_side;
+        if (t.skip_below > 0) {
+            const int side = v.ny > v.nx ? v.ny : v.nx;
+            v.skip = !v.ok || side <= t.skip_below;
+            v.ok = v.ok && !v.skip;
+        }
     } else {
         v.off = p * ((int64_t)ny * nx);
         v.ny = ny;
@@ -1681,7 +1692,7 @@ SPX_TKERNEL(256) void disp5_kernel(const TIn* __restrict__ ref, const TIn* __res
     load_twiddles<C>(lds, tw_g);
     for (int64_t p = first_item(rt::block_id(), rt::grid_size()); p < nbatch; p += rt::grid_size()) {
         const ItemView it = item_view(items, p, ny, nx);
-        if (!it.ok) { item_refused(out, status, p, rt::thread_id() == 0); continue; }
+        if (!it.ok) { if (!it.skip) item_refused(out, status, p, rt::thread_id() == 0); continue; }
         disp5_body<C, FOLD, TIn>(ref + it.off, im4 + 4 * it.off, it.ny, it.nx, cc_type, tw_g,
                       icc + 4 * it.off, out + 2 * p, status ? status + p : nullptr, lds);
         rt::block_sync_lds();

@@ -503,7 +503,7 @@ SPX_TKERNEL(256) void disp5_32_kernel(const TIn* __restrict__ ref, const TIn* __
     for (int64_t p = first_item(rt::block_id(), rt::grid_size()) * 4 + wave; p < nbatch; p += rt::grid_size() * 4) {
         const int lane = fresh_tid() & 63;
         const ItemView it = item_view(items, p, ny_u, nx_u);       // per-item shape (see spx_kernels.h)
-        if (!it.ok) { item_refused(out_all, status, p, lane == 0); continue; }
+        if (!it.ok) { if (!it.skip) item_refused(out_all, status, p, lane == 0); continue; }
         ny = it.ny;
         nx = it.nx;
         const int64_t stride = (int64_t)ny * nx;

@@ -16,8 +16,8 @@ import torch
 
 from . import _ffi, device
 
-__all__ = ['Cutout', 'NoOverlapError', 'PartialOverlapError', 'pack_cutouts',
-           'segment_bounding_boxes', 'primary_cutout_boxes']
+__all__ = ['Cutout', 'CutoutCatalog', 'PackedImages', 'NoOverlapError', 'PartialOverlapError', 'pack_cutouts',
+           'pack_cutouts_var', 'segment_bounding_boxes', 'primary_cutout_boxes']
 
 
 class NoOverlapError(ValueError):
@@ -330,3 +330,174 @@ def pack_cutouts(frame, boxes, tile, mask=None, fill=0.0, segmentation_image=Non
                                               device.ptr(tiles), device.ptr(sg), device.ptr(si),
                                               device.stream_ptr()))
     return tiles
+
+
+def _item_tables(shapes):
+    """(offsets int64 [N], total) of items packed back to back; ``shapes`` int [N, 2] = (h, w)."""
+    sizes = shapes[:, 0].astype(np.int64) * shapes[:, 1].astype(np.int64)
+    offs = np.zeros(len(sizes), dtype=np.int64)
+    if len(sizes) > 1:
+        np.cumsum(sizes[:-1], out=offs[1:])
+    return offs, int(sizes.sum())
+
+
+def pack_cutouts_var(frame, boxes, mask=None, fill=0.0, segmentation_image=None, ids=None, _tables=None):
+    """Gather windows of DIFFERENT shapes of ``frame`` into one packed float32 device buffer
+    (``spx_gather_cutouts_var_f32``): item ``k`` = ``boxes[k] = (x0, y0, width, height)`` occupies
+    ``packed[offsets[k] : offsets[k] + height * width]``, row-major.  ``fill``, ``mask``,
+    ``segmentation_image`` / ``ids`` as :func:`pack_cutouts`.
+
+    Returns ``(packed, offsets, shapes)``: CUDA tensors (float32 [total], int64 [N], int32 [N, 2] = (h, w))."""
+    f = device.to_device(frame, torch.float32)
+    boxes = np.ascontiguousarray(boxes, dtype=np.int32)
+    if f.dim() != 2 or boxes.ndim != 2 or boxes.shape[1] != 4:
+        raise ValueError("frame must be 2-D and boxes [N, 4].")
+    if (boxes[:, 2:] < 1).any():
+        raise ValueError("Ill-formed extraction box: width and height must be positive.")
+    m = None if mask is None else device.to_device(mask, torch.uint8)
+    if m is not None and tuple(m.shape) != tuple(f.shape):
+        raise ValueError("mask must have the shape of the frame.")
+    if (segmentation_image is None) != (ids is None):
+        raise ValueError("segmentation_image and ids must be given together.")
+    sg = None if segmentation_image is None else device.to_device(segmentation_image, torch.int32)
+    si = None if ids is None else device.to_device(ids if isinstance(ids, torch.Tensor) else np.asarray(ids, dtype=np.int32),
+                                                   torch.int32)
+    if _tables is None:
+        shapes = np.ascontiguousarray(boxes[:, [3, 2]])
+        offs, total = _item_tables(shapes)
+        _tables = (torch.from_numpy(boxes).to(f.device), torch.from_numpy(offs).to(f.device),
+                   torch.from_numpy(shapes).to(f.device), total)
+    b_d, o_d, s_d, total = _tables
+    packed = torch.empty((max(total, 1),), dtype=torch.float32, device=f.device)
+    lib = _ffi.load()
+    with torch.cuda.device(f.device):
+        _ffi.check(lib.spx_gather_cutouts_var_f32(device.ptr(f), device.ptr(m), f.shape[0], f.shape[1],
+                                                  device.ptr(b_d), boxes.shape[0], device.ptr(o_d), float(fill),
+                                                  device.ptr(packed), device.ptr(sg), device.ptr(si),
+                                                  device.stream_ptr()))
+    return packed, o_d, s_d
+
+
+class PackedImages(object):
+    """Read-only sequence of 2-D float32 images stored back to back in one device buffer (what the
+    catalog path of ``find_linear_fit`` returns for the interlaced cross-correlation images and the
+    non-shifted blots).  ``images[k]`` is a numpy array; the buffer is copied to the host once, on first
+    access -- a caller that never looks at them (the fit itself does not) pays nothing."""
+
+    def __init__(self, buf, offsets, shapes, scale=1, stride=1, part=0):
+        self._buf, self._host = buf, None
+        self._off = np.asarray(offsets, dtype=np.int64) * scale
+        self._shp = np.asarray(shapes, dtype=np.int64)
+        self._stride, self._part = stride, part         # blots: 4 images per item, `part` selects one
+
+    def __len__(self):
+        return len(self._off)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        if self._host is None:
+            self._host = self._buf.cpu().numpy()
+        k = int(k) + (len(self) if k < 0 else 0)
+        h, w = self._shp[k]
+        o = self._off[k] + self._part * h * w
+        return self._host[o:o + h * w].reshape(h, w)
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+
+class CutoutCatalog(object):
+    """All cutouts of ONE image for a catalog of sources: the frame stays on the device and the cutouts are
+    described by an ``[N, 4]`` box table instead of N Python objects holding N array copies.
+
+    It is a sequence of :class:`Cutout` -- ``catalog[k]`` builds the k-th one on demand with the reference's
+    constructor semantics (cutout.py:689-797, ``mode='fill'``) -- so code written against lists of cutouts
+    keeps working, while :func:`subpixal_amd.align.find_linear_fit` recognises a catalog and runs the whole
+    loop of align.py:656-699 on the device (one gather, one blot and one cross-correlation launch per
+    kernel family for all sources).
+
+    frame : 2-D array (numpy or CUDA tensor).   boxes : int ``[N, 4]`` rows ``(x0, y0, width, height)``.
+    src_pos : ``[N, 2]`` source positions in frame coordinates (default: box centres).
+    src_weight : ``[N]`` or None.   src_id : ``[N]`` labels in ``segmentation_image`` (default 1..N).
+    mask : bad-pixel booleans of the frame (True = bad).  segmentation_image : label image; pixels of a box
+    carrying another label count as masked (cutout.py:190).  fillval : value of pixels outside the frame.
+    """
+
+    def __init__(self, frame, boxes, src_pos=None, src_weight=None, src_id=None, mask=None,
+                 segmentation_image=None, wcs=None, fillval=np.nan, exptime=1, data_units='rate'):
+        self.boxes = np.ascontiguousarray(boxes, dtype=np.int32)
+        if self.boxes.ndim != 2 or self.boxes.shape[1] != 4:
+            raise ValueError("boxes must have shape [N, 4].")
+        if (self.boxes[:, 2:] < 1).any():
+            raise ValueError("Ill-formed extraction box: width and height must be positive.")
+        n = len(self.boxes)
+        self.frame = device.to_device(frame, torch.float32)
+        if self.frame.dim() != 2:
+            raise ValueError("frame must be 2-D.")
+        self._frame_host = frame if isinstance(frame, np.ndarray) else None
+        self._tables = None
+        self.mask = None if mask is None else device.to_device(mask, torch.uint8)
+        self.segmentation_image = None if segmentation_image is None else \
+            device.to_device(segmentation_image, torch.int32)
+        self.wcs = wcs
+        self.fillval = fillval
+        self.exptime = exptime
+        self.data_units = data_units
+        b = self.boxes.astype(np.float64)
+        self.src_pos = (np.stack([b[:, 0] + 0.5 * (b[:, 2] - 1), b[:, 1] + 0.5 * (b[:, 3] - 1)], axis=1)
+                        if src_pos is None else np.asarray(src_pos, dtype=np.float64).reshape(n, 2))
+        self.src_weight = None if src_weight is None else np.asarray(src_weight, dtype=np.float64).reshape(n)
+        if self.src_weight is not None and (self.src_weight < 0).any():
+            raise ValueError("Source weight must be a non-negative number or None.")
+        self.src_id = np.arange(1, n + 1, dtype=np.int32) if src_id is None else \
+            np.asarray(src_id, dtype=np.int32).reshape(n)
+
+    def __len__(self):
+        return len(self.boxes)
+
+    @property
+    def shapes(self):
+        """``[N, 2]`` int32 (height, width)."""
+        return np.ascontiguousarray(self.boxes[:, [3, 2]])
+
+    def _host_frame(self):
+        if self._frame_host is None:
+            self._frame_host = self.frame.cpu().numpy()
+        return self._frame_host
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        k = int(k) + (len(self) if k < 0 else 0)
+        x0, y0, w, h = (int(v) for v in self.boxes[k])
+        ct = Cutout(self._host_frame(), self.wcs, blc=(x0, y0), trc=(x0 + w - 1, y0 + h - 1),
+                    src_pos=tuple(self.src_pos[k]),
+                    src_weight=None if self.src_weight is None else float(self.src_weight[k]),
+                    src_id=int(self.src_id[k]), data_units=self.data_units, exptime=self.exptime,
+                    mode='fill', fillval=self.fillval)
+        for extra, test in ((self.mask, lambda a: np.asarray(a, bool)),
+                            (self.segmentation_image, lambda a: np.asarray(a) != int(self.src_id[k]))):
+            if extra is not None:
+                ex = extra.cpu().numpy() if isinstance(extra, torch.Tensor) else np.asarray(extra)
+                ct.mask[ct.insertion_slice] |= test(ex[ct.extraction_slice])
+        return ct
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+    def packed(self, zero_masked=False):
+        """``(packed, offsets, shapes)`` device tensors of all cutouts (:func:`pack_cutouts_var`).
+        zero_masked False: the cutouts' ``data`` -- frame pixels, ``fillval`` outside the frame;
+        True: masked pixels (mask, other segments, non-finite, outside) zeroed, i.e. after align.py:661."""
+        if self._tables is None:           # the box / offset / shape tables go to the device once
+            shapes = self.shapes
+            offs, total = _item_tables(shapes)
+            dev = self.frame.device
+            self._tables = (torch.from_numpy(self.boxes).to(dev), torch.from_numpy(offs).to(dev),
+                            torch.from_numpy(shapes).to(dev), total)
+            self._ids_dev = torch.from_numpy(self.src_id).to(dev)
+        if zero_masked:
+            return pack_cutouts_var(self.frame, self.boxes, self.mask, 0.0, self.segmentation_image,
+                                    None if self.segmentation_image is None else self._ids_dev, self._tables)
+        return pack_cutouts_var(self.frame, self.boxes, None, self.fillval, _tables=self._tables)

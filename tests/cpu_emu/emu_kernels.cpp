@@ -196,7 +196,7 @@ static int emu_disp5_t(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, i
     if (ny < 3 || nx < 3) return -1;
     const int n = ny > nx ? ny : nx;
     if (off && n > 128) return -1;
-    const ItemTable items = {off, shp, n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 85 ? 85 : 128))};
+    const ItemTable items = {off, shp, n <= 32 ? 32 : (n <= 64 ? 64 : (n <= 85 ? 85 : 128)), 0};
     if (n > 128) {
         const int C = big_class_count(ny, nx);
         if (C > kBigMaxC) return -1;
