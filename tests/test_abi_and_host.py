@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_ffi.EXPORTED_SYMBOLS) == names
-    assert lib.spx_abi_version() == 2
+    assert lib.spx_abi_version() == _ffi.ABI_VERSION == 3
 
 
 def test_argument_errors_without_gpu():
