@@ -99,6 +99,7 @@ extern "C" {
 /* largest cutout side and upsampling factor the kernels accept */
 #define SPX_MAX_SIDE 682
 #define SPX_MAX_UPSAMPLE 59
+#define SPX_MAX_UPSAMPLE_GENERAL 39 /* pair mode on cutouts above 128 px (float32 transforms: see spx_xcorr_refine_f32) */
 
 int spx_abi_version(void);
 int spx_device_count(void);
@@ -143,7 +144,8 @@ size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int nee
  *   out_status : int32   [nbatch]     SPX_ST_* ; may be NULL
  * 5 <= ny, nx <= SPX_MAX_SIDE (cutouts above 128 px take the slow general path: the reference's
  * cutouts, bounding box + padding of a segment, have no upper bound, cutout.py:159-175);
- * 1 <= upsample <= SPX_MAX_UPSAMPLE.
+ * 1 <= upsample <= SPX_MAX_UPSAMPLE (cutouts above 128 px: <= SPX_MAX_UPSAMPLE_GENERAL -- their wide, flat
+ * correlation peaks reached 1.2e-3 px against the float64 definition at upsample >= 40, past the 1e-3 px promised).
  */
 int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
                          int upsample, int cc_type, double* out_dxdy, int32_t* out_status,

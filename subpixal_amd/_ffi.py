@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get('SPX_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libsubp
 ABI_VERSION = 3
 MAX_SIDE = 682
 MAX_UPSAMPLE = 59
+MAX_UPSAMPLE_GENERAL = 39      # cutouts above 128 px
 
 CC_CODES = {'CC': 0, 'NCC': 1, 'ZNCC': 2}
 

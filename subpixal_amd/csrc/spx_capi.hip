@@ -430,6 +430,11 @@ int xcorr_refine(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
     TableLock lk;
     if (!t->ready) return fail(SPX_E_ARG, "spx_shutdown() ran between the call's start and its launch");
     if (tile == TILE_BIG) {            // general path: class count and tables at run time
+        // Above 128 px the float32 transforms limit the refinement at very fine grids: 11..25-px-wide spots
+        // at upsample >= 40 reached 1.2e-3 px against the float64 definition (profiles/r02/sweeps_late.txt),
+        // past the 1e-3 px this library promises -- refused rather than returned out of tolerance.
+        if (upsample > SPX_MAX_UPSAMPLE_GENERAL)
+            return fail(SPX_E_SHAPE, "cutouts above 128 px take upsample 1..39");
         const int C = spx::big_class_count(ny, nx);
         const spx::cf* tw = nullptr;
         rc = big_tables_for(t, C, upsample, &tw, &a.ktab);

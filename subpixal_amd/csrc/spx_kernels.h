@@ -1594,10 +1594,16 @@ SPX_DEVICE void disp5_body(const TIn* __restrict__ ref, const TIn* __restrict__ 
                            float* __restrict__ icc, double* __restrict__ out,
                            int* __restrict__ status, unsigned char* lds) {
     typedef Lds<C> L;
-    const int tid = rt::thread_id();
     unsigned char* scr = lds + L::SCR_OFF;
     const int64_t stride = (int64_t)ny * nx;
-    const NormStatsT<TIn> ns = norm_stats(scr, ref, im4, 4, stride, ny, nx, cc_type);
+    NormStatsT<TIn> ns = norm_stats(scr, ref, im4, 4, stride, ny, nx, cc_type);
+    // workgroup-uniform values -> scalar registers: they live across the four dithers' transforms, where
+    // every vector register is taken (6-11 spilled VGPRs before, tools/kernel_regs.py)
+    ns.im_mean = rt::read_lane(ns.im_mean, 0);
+    ns.im_std = rt::read_lane(ns.im_std, 0);
+    ns.ref_mean = rt::read_lane(ns.ref_mean, 0);
+    ns.ref_std = rt::read_lane(ns.ref_std, 0);
+    ns.active = rt::read_lane(ns.active, 0);
 
     float bv = -__builtin_inff();
     int bi = 0x7fffffff;
@@ -1625,7 +1631,7 @@ SPX_DEVICE void disp5_body(const TIn* __restrict__ ref, const TIn* __restrict__ 
     } else {
         pk = peak_from_argmax(scr, imax, jmax, NX, NY, [&](int x, int y) { return icc[y * NX + x]; });
     }
-    if (tid == 0) {
+    if (fresh_tid() == 0) {
         out[0] = 0.5 * pk.x - (double)((NX - 1) / 4);     // cc.py:89-93
         out[1] = 0.5 * pk.y - (double)((NY - 1) / 4);
         if (status) status[0] = pk.status;

@@ -178,6 +178,7 @@ SPX_DEVICE void class_round128(unsigned char* lds, const TIn* __restrict__ ref,
     }
     rt::block_sync_lds();      // every wave has read the slab before any transposition overwrites it
     clk.tick(1);
+    rt::set_prio<0>();         // transforms: throughput work (see spx_rt_hip.h set_prio)
     // class pre-twiddle w_P^{c (8 y1)}
     if (cy) {
 #pragma unroll
@@ -242,6 +243,7 @@ SPX_DEVICE void class_round128(unsigned char* lds, const TIn* __restrict__ ref,
         }
     }
     clk.tick(2);
+    rt::set_prio<1>();         // stores, staging, combine, refine: latency-bound
     // g_c -> workspace planes [class][re|im][64][64], through the wave's LDS buffer so the
     // global stores are 16-byte, row-contiguous.  Two economies (C = 3):
     //  * the real plane of class (0,0) is never written: its twiddle is 1 for every block, so
@@ -460,6 +462,12 @@ SPX_DEVICE void fine_window128(unsigned char* lds, const double* __restrict__ kt
 #pragma unroll
         for (int t = 0; t < TPW; ++t) acc[ab][t] = f64x4{0., 0., 0., 0.};
     const int col0 = L::wrap(lxc + CW * wave + TPW * lj - L::P / 2);     // + t (wrap copy in the row)
+    // the convolution rows come from the workspace (Infinity Cache at best: ~600 cycles): the loads of step
+    // s4 + 1 are issued before the matrix products of step s4
+    RowFrag<TPW> nxt[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        nxt[e] = *reinterpret_cast<const RowFrag<TPW>*>(conv + (size_t)L::wrap(lyc + 4 * e + lk - L::P / 2) * L::CS + col0);
 #pragma unroll 4
     for (int s4 = 0; s4 < NQ; ++s4) {
         double kb[WB][4];
@@ -470,9 +478,13 @@ SPX_DEVICE void fine_window128(unsigned char* lds, const double* __restrict__ kt
         }
         RowFrag<TPW> a4[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = L::wrap(lyc + 4 * (4 * s4 + e) + lk - L::P / 2);
-            a4[e] = *reinterpret_cast<const RowFrag<TPW>*>(conv + (size_t)row * L::CS + col0);
+        for (int e = 0; e < 4; ++e) a4[e] = nxt[e];
+        if (s4 + 1 < NQ) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = L::wrap(lyc + 4 * (4 * (s4 + 1) + e) + lk - L::P / 2);
+                nxt[e] = *reinterpret_cast<const RowFrag<TPW>*>(conv + (size_t)row * L::CS + col0);
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)

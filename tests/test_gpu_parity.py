@@ -327,6 +327,14 @@ def test_shape_and_upsample_limits(spx):
         spx.xcorr_refine_batch(b, b, upsample=60)
     with pytest.raises(SubpixalHipError):
         spx.xcorr_refine_batch(b[:, :4], b[:, :4])
+    # cutouts above 128 px: upsample up to SPX_MAX_UPSAMPLE_GENERAL = 39 (finer grids left the 1e-3 px
+    # tolerance there in round 2's sweeps and are refused instead)
+    c = np.zeros((1, 130, 64), np.float32)
+    c[0, 60:70, 30:36] = 1.0
+    with pytest.raises(SubpixalHipError, match='1..39'):
+        spx.xcorr_refine_batch(c, c, upsample=40)
+    assert spx.xcorr_refine_batch(c, c, upsample=39).shape == (1, 2)
+    assert spx.xcorr_refine_batch(c[:, :128], c[:, :128], upsample=59).shape == (1, 2)
     out = spx.xcorr_refine_batch(b[:0], b[:0])
     assert out.shape == (0, 2)
 
