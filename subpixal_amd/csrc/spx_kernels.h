@@ -590,11 +590,19 @@ SPX_DEVICE void chunk_unpack(const ChunkLoad<TIn>& c, const NormStatsT<TIn>& ns,
 // zero padding in an 88 x 88 region of row stride 88 (8 consecutive columns of 8 consecutive
 // rows fall into 64 distinct banks for both strides); the four parity classes then read
 // z[y][x] +- z[y][x+64] +- z[y+64][x] +- z[y+64][x+64] (cc_planes).
+// Cutouts up to 64 px (round 3): a row is stored PERMUTED -- pixel x = x0 + 8 x1 at float x0 * PS12 + x1,
+// PS12 = 12 -- so that the eight stride-8 samples a lane's registers take from a row (round A of cc_planes:
+// lane (y0, x0), registers (y1, x1)) are contiguous: two 16-byte LDS reads per row and plane instead of eight
+// 4-byte ones (128 -> 32 read instructions per wave and pair).  With a row stride of 96 floats the 16-byte reads
+// are bank-conflict free and the (now 4-byte) staging writes 2-way, which costs them nothing (brute-forced).
 template <int C, bool FOLD> struct StageGeom {
-    static constexpr int ZS = FOLD ? 88 : Lds<C>::ZS;
+    static constexpr int ZS = FOLD ? 88 : 96;
     static constexpr int ROWS = FOLD ? 88 : 64;
     static constexpr int CHUNKS = (FOLD ? 88 : 64) / 4;        // 4-pixel chunks per staged row
-    static_assert(2 * ROWS * ZS * 4 <= Lds<C>::XCH_BYTES || !FOLD, "fold staging must fit the exchange region");
+    static constexpr int PS12 = 12;                            // floats per x0 slot of a permuted row
+    static_assert(2 * ROWS * ZS * 4 <= Lds<C>::XCH_BYTES, "the staged input must fit the exchange region it shares");
+    // float offset inside a permuted row of pixel x = 4 q + e (q: chunk index)
+    static SPX_DEVICE int perm(int q, int e) { return (4 * (q & 1) + e) * PS12 + (q >> 1); }
 };
 
 // ssq[0] += sum ref^2, ssq[1] += sum img^2 over this thread's pixels (as staged).
@@ -617,7 +625,7 @@ SPX_DEVICE void stage_pair_rows(unsigned char* lds, const TIn* __restrict__ ref,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + i * kThreads;            // 1024 float4 per image
-            const int y = idx >> 4, x4 = (idx & 15) << 2;
+            const int y = idx >> 4;
             f32x4 r = r4[idx];
             const f32x4 t = m4[(63 - y) * 16 + (15 - (idx & 15))];
             f32x4 m = f32x4{t[3], t[2], t[1], t[0]};
@@ -628,10 +636,13 @@ SPX_DEVICE void stage_pair_rows(unsigned char* lds, const TIn* __restrict__ ref,
                     r[e] = norm_ref(r[e], ns);
                 }
             }
-            *reinterpret_cast<f32x4*>(zre + y * L::ZS + x4) = r;
-            *reinterpret_cast<f32x4*>(zim + y * L::ZS + x4) = m;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { sr += r[e] * r[e]; sm += m[e] * m[e]; }
+            for (int e = 0; e < 4; ++e) {
+                zre[y * G::ZS + G::perm(idx & 15, e)] = r[e];
+                zim[y * G::ZS + G::perm(idx & 15, e)] = m[e];
+                sr += r[e] * r[e];
+                sm += m[e] * m[e];
+            }
         }
         ssq[0] = sr;
         ssq[1] = sm;
@@ -657,8 +668,16 @@ SPX_DEVICE void stage_pair_rows(unsigned char* lds, const TIn* __restrict__ ref,
         const int x = (FOLD ? idx - y * G::CHUNKS : (idx & 15)) << 2;
         float rr[4], mm[4];
         chunk_unpack(ld[i], ns, rr, mm);
-        *reinterpret_cast<f32x4*>(zre + y * G::ZS + x) = f32x4{rr[0], rr[1], rr[2], rr[3]};
-        *reinterpret_cast<f32x4*>(zim + y * G::ZS + x) = f32x4{mm[0], mm[1], mm[2], mm[3]};
+        if constexpr (FOLD) {
+            *reinterpret_cast<f32x4*>(zre + y * G::ZS + x) = f32x4{rr[0], rr[1], rr[2], rr[3]};
+            *reinterpret_cast<f32x4*>(zim + y * G::ZS + x) = f32x4{mm[0], mm[1], mm[2], mm[3]};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                zre[y * G::ZS + G::perm(x >> 2, e)] = rr[e];
+                zim[y * G::ZS + G::perm(x >> 2, e)] = mm[e];
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sr += rr[e] * rr[e]; sm += mm[e] * mm[e]; }
     }
@@ -746,8 +765,22 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
     // FOLD: the class's radix-2 fold of the samples beyond index 63 (they exist for
     // y, x < 24 only: the cutout ends before 88)
     const float fsx = cx ? -1.0f : 1.0f, fsy = cy ? -1.0f : 1.0f;
+    if constexpr (!FOLD) {
+        // permuted rows (StageGeom): the lane's eight samples of a row are 32 contiguous bytes per plane
 #pragma unroll
-    for (int y1 = 0; y1 < 8; ++y1)
+        for (int y1 = 0; y1 < 8; ++y1) {
+            const f32x4* pr = reinterpret_cast<const f32x4*>(zre + (l1 + 8 * y1) * G::ZS + l0 * G::PS12);
+            const f32x4* pi = reinterpret_cast<const f32x4*>(zim + (l1 + 8 * y1) * G::ZS + l0 * G::PS12);
+            const f32x4 r0 = pr[0], r1 = pr[1], i0 = pi[0], i1 = pi[1];
+#pragma unroll
+            for (int x1 = 0; x1 < 4; ++x1) {
+                v[y1][x1] = cf{r0[x1], bal * i0[x1]};
+                v[y1][x1 + 4] = cf{r1[x1], bal * i1[x1]};
+            }
+        }
+    }
+#pragma unroll
+    for (int y1 = 0; y1 < (FOLD ? 8 : 0); ++y1)
 #pragma unroll
         for (int x1 = 0; x1 < 8; ++x1) {
             const int a = (l1 + 8 * y1) * G::ZS + l0 + 8 * x1;

@@ -137,9 +137,10 @@ SPX_DEVICE void class_round128(unsigned char* lds, const TIn* __restrict__ ref,
     typedef LdsBig<C> L;
     static_assert(C == 3 || C == 4, "");
     const int tid = fresh_tid();
-    const int wave = tid >> 6, lane = tid & 63;
-    // C = 3: the fourth wave has no class of its own; it runs class (cy, 0) along (no divergent
-    // control flow around the FFT, which would cost registers) and only its stores are skipped
+    const int wave = rt::read_lane(tid >> 6, 0), lane = tid & 63;      // (scalar: the branches on it are uniform)
+    // C = 3: the fourth wave has no class of its own.  It used to run class (cy, 0) along, storing nothing;
+    // since round 3 it skips the transforms (SPX_IDLE_WAVE_SKIPS, a wave-uniform branch) and leaves its SIMD's
+    // issue slots to the other workgroup's waves.
     const bool active = C == 4 || wave < C;
     const int cx = active ? wave : 0;
     const int l1 = lane >> 3, l0 = lane & 7;
@@ -179,6 +180,9 @@ SPX_DEVICE void class_round128(unsigned char* lds, const TIn* __restrict__ ref,
     rt::block_sync_lds();      // every wave has read the slab before any transposition overwrites it
     clk.tick(1);
     rt::set_prio<0>();         // transforms: throughput work (see spx_rt_hip.h set_prio)
+#ifndef SPX_IDLE_WAVE_SHADOWS
+    if (active) {
+#endif
     // class pre-twiddle w_P^{c (8 y1)}
     if (cy) {
 #pragma unroll
@@ -242,6 +246,9 @@ SPX_DEVICE void class_round128(unsigned char* lds, const TIn* __restrict__ ref,
             v[y1][x1] = cmulc(cmulc(v[y1][x1], wy), wx);
         }
     }
+#ifndef SPX_IDLE_WAVE_SHADOWS
+    }
+#endif
     clk.tick(2);
     rt::set_prio<1>();         // stores, staging, combine, refine: latency-bound
     // g_c -> workspace planes [class][re|im][64][64], through the wave's LDS buffer so the
