@@ -3,6 +3,7 @@
 #include "spx_rt_hip.h"
 #include "spx_kernels.h"
 #include "spx_kernels8.h"
+#include "spx_kernels5.h"
 #include "spx_kernels128.h"
 #include "spx_kernels_big.h"
 #include "spx_kernels32.h"
@@ -17,6 +18,9 @@
 #include <string>
 #include <vector>
 
+#ifndef SPX_DISP5_PACKED_DEFAULT
+#define SPX_DISP5_PACKED_DEFAULT 1
+#endif
 #ifndef SPX_PAIR64_WAVES_DEFAULT
 #define SPX_PAIR64_WAVES_DEFAULT 4      // measured: 25.2e6 pairs/s on 4 waves, 18.2e6 on 8 (profiles/r03)
 #endif
@@ -346,6 +350,29 @@ int run_disp5(DeviceTables* t, Tile tile, bool fold, const TIn* ref, const TIn* 
                            im4, a.nbatch, a.ny, a.nx, a.cc_type, t->tw[TILE32], a.icc, a.out, a.status, a.items);
         SPX_HIP(hipGetLastError());
         return 0;
+    }
+    // 64 tile: the packed kernel (five transforms per source, one workgroup per CU: spx_kernels5.h) or the
+    // round-2 one (eight, two per CU).  Measured (profiles/r03/disp5_packed_ab*.txt): packed is 10 % faster for
+    // plain CC up to 64 px and slower where a second memory-bound pass runs uncovered on a CU with one workgroup
+    // (the statistics of NCC / ZNCC: -4 %) and on the fold path (-5 %): it takes plain CC up to 64 px.
+    // SPX_DISP5_PACKED = 0 never | 1 that rule (default) | 2 always  (A/B knob, read once)
+    static const int mode = [] {
+        const char* e = getenv("SPX_DISP5_PACKED");
+        const int v = e ? atoi(e) : SPX_DISP5_PACKED_DEFAULT;
+        return v < 0 || v > 2 ? 1 : v;
+    }();
+    const bool packed = mode == 2 || (mode == 1 && a.cc_type == 0 && !fold);
+    {
+        const int lds5 = fold ? spx::p5::L5<true>::TOTAL : spx::p5::L5<false>::TOTAL;
+        auto k5 = fold ? spx::p5::disp5p_kernel<true, TIn> : spx::p5::disp5p_kernel<false, TIn>;
+        int rc5 = allow_lds(t, k5, lds5);
+        if (rc5) return rc5;
+        if (launch && packed) {
+            hipLaunchKernelGGL(k5, dim3(grid_for(t, a.nbatch)), dim3(spx::kThreads), lds5, a.s, ref, im4, a.nbatch,
+                               a.ny, a.nx, a.cc_type, t->tw[TILE64], a.icc, a.out, a.status, a.items);
+            SPX_HIP(hipGetLastError());
+            return 0;
+        }
     }
     const int lds = spx::Lds<2>::total(0);
     auto kern = fold ? spx::disp5_kernel<2, true, TIn> : spx::disp5_kernel<2, false, TIn>;

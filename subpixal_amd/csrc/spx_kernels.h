@@ -496,6 +496,7 @@ template <typename T> struct NormStatsT {
 template <typename T> struct Quad { T v[4]; };
 struct __attribute__((packed, aligned(4))) PackedF4 { float v[4]; };
 struct __attribute__((packed, aligned(8))) PackedD2 { double v[2]; };
+struct __attribute__((packed, aligned(4))) PackedF2 { float v[2]; };      // 8-byte access, 4-byte aligned
 SPX_DEVICE Quad<float> load_quad(const float* p) {
     const PackedF4 t = *reinterpret_cast<const PackedF4*>(p);
     return Quad<float>{{t.v[0], t.v[1], t.v[2], t.v[3]}};

@@ -17,6 +17,8 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define SPX_TKERNEL(nthreads) __global__ __launch_bounds__(nthreads, 2)
 // 512-thread workgroups, two per CU: four waves per SIMD, at most 128 VGPRs
 #define SPX_TKERNEL8(nthreads) __global__ __launch_bounds__(nthreads, 4)
+// one wave per SIMD: up to 512 registers per lane (spx_kernels5.h keeps two class tiles resident)
+#define SPX_TKERNEL1(nthreads) __global__ __launch_bounds__(nthreads, 1)
 // all LDS lives in ONE dynamic region (cdna guide G17: keep the base 16-B aligned)
 #define SPX_STATIC_LDS(type, name, count) __shared__ type name[count]
 #define SPX_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]

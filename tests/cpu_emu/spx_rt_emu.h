@@ -28,6 +28,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define SPX_KERNEL(nthreads) extern "C"
 #define SPX_TKERNEL(nthreads)
 #define SPX_TKERNEL8(nthreads)
+#define SPX_TKERNEL1(nthreads)
 #define SPX_STATIC_LDS(type, name, count) static type name[count]
 #define SPX_DYN_LDS(name) unsigned char* name = ::spx::rt::emu().lds
 

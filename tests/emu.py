@@ -38,6 +38,12 @@ def set_grid(g):
     lib().emu_set_grid(ctypes.c_int64(g))
 
 
+def set_disp5_packed(v):
+    """64-tile reference-mode kernel: 0 round 2's, 1 the product's rule (the five-transform kernel of
+    spx_kernels5.h for plain CC up to 64 px), 2 always the five-transform one"""
+    lib().emu_set_disp5_packed(int(v))
+
+
 def first_item(b, nwg):
     fn = lib().emu_first_item
     fn.restype = ctypes.c_int64

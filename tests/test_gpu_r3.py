@@ -118,3 +118,36 @@ def test_eight_wave_kernel_through_the_c_abi(spx):
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert 'eight-wave kernel OK' in out.stdout
+
+
+_PACKED_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + '/tests')
+import datagen, subpixal_amd as spx
+from oracle import subpixal_oracle as orc
+g = np.load(%(root)r + '/tests/golden/find_displacement.npz', allow_pickle=False)
+for n, shape, name, dt in ((64, None, 'NCC', np.float32), (64, None, 'CC', np.float32), (48, None, 'ZNCC', np.float64),
+                           (77, None, 'NCC', np.float32), (85, None, 'CC', np.float64), (40, (33, 40), 'ZNCC', np.float32),
+                           (5, (3, 5), 'CC', np.float32)):
+    r5, m4, _ = datagen.dither_batch(7, 6, n, dtype=dt)
+    if shape:
+        r5 = np.ascontiguousarray(r5[:, :shape[0], :shape[1]]); m4 = np.ascontiguousarray(m4[:, :, :shape[0], :shape[1]])
+    d, icc, st = spx.find_displacement_batch(r5, m4, cc_type=name, full_output=True, return_status=True)
+    e, est = orc.find_displacement_batch(r5, m4, name)
+    assert np.array_equal(st, est), (n, name)
+    assert np.abs(d - e).max() < 3e-5, (n, name, np.abs(d - e).max())
+    eicc = orc.build_icc(r5[0], *m4[0], cc_type=name)[0]
+    assert np.abs(icc[0] - eicc).max() < 3e-6 * np.abs(eicc).max()
+print('five-transform kernel OK')
+'''
+
+
+def test_five_transform_reference_mode_kernel_for_every_cc_type(spx):
+    """SPX_DISP5_PACKED=2 (read once per process, hence the child): spx_kernels5.h takes every 64-tile
+    reference-mode call -- NCC / ZNCC, float64 inputs, the fold path and ragged shapes too, not only the plain
+    CC it is the default for -- against the oracle's cc.find_displacement (cc.py:21-95)."""
+    env = dict(os.environ, SPX_DISP5_PACKED='2')
+    out = subprocess.run([sys.executable, '-c', _PACKED_CHILD % {'root': ROOT}], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert 'five-transform kernel OK' in out.stdout

@@ -67,6 +67,38 @@ def test_pair_mode_eight_wave_kernel():
     assert st[0] == 6 and st[1] == 0 and got[0, 0] == -31.0
 
 
+def test_reference_mode_five_transform_kernel():
+    """spx_kernels5.h: R = FFT(ref) once, the dithers transformed two at a time, both correlations of a pair
+    from one inverse -- against the oracle's cc.find_displacement (cc.py:21-95) for every cc_type, float64
+    inputs, ragged shapes and the fold path; and equal (to float32 rounding) to the eight-transform kernel"""
+    try:
+        for n, shape, cc, dt in ((64, None, 1, np.float32), (48, None, 2, np.float32), (64, None, 0, np.float64),
+                                 (77, None, 1, np.float32), (85, None, 2, np.float32), (40, (33, 40), 0, np.float32)):
+            r5, m4, _ = datagen.dither_batch(3, 2, n, dtype=dt)
+            if shape:
+                r5 = np.ascontiguousarray(r5[:, :shape[0], :shape[1]])
+                m4 = np.ascontiguousarray(m4[:, :, :shape[0], :shape[1]])
+            emu.set_disp5_packed(2)
+            d, st, icc = emu.disp5(r5, m4, cc)
+            emu.set_disp5_packed(0)
+            d0, st0, icc0 = emu.disp5(r5, m4, cc)
+            e, est = orc.find_displacement_batch(r5, m4, datagen.CC_TYPES[cc])
+            eicc = orc.build_icc(r5[0], *m4[0], cc_type=datagen.CC_TYPES[cc])[0]
+            assert np.array_equal(st, est) and np.array_equal(st0, est)
+            assert np.abs(d - e).max() < 2e-5 and np.abs(d - d0).max() < 2e-5, (n, cc, np.abs(d - e).max())
+            assert np.abs(icc[0] - eicc).max() < 3e-6 * np.abs(eicc).max()
+    finally:
+        emu.set_disp5_packed(1)
+    bad = r5.copy()
+    bad[0, 3, 3] = np.nan
+    emu.set_disp5_packed(2)
+    try:
+        d, st, _ = emu.disp5(bad, m4, 0)
+    finally:
+        emu.set_disp5_packed(1)
+    assert st[0] == 6 and st[1] == 0
+
+
 def test_item_walk_is_a_bijection_and_keeps_runs_of_eight_on_one_l2():
     """first_item (spx_kernels.h): workgroup -> first item of its grid-stride walk.  Every grid size
     must visit each item exactly once; launches of a multiple of 64 workgroups hand workgroups
