@@ -254,12 +254,14 @@ def reference_mode_block(dev, steps, warmup):
     rate = N / (ms * 1e-3)
     pmc, src = _profile_json('pmc_traffic_disp5_64.json')
     traffic = pmc['hbm_bytes_per_launch'] if pmc is not None and pmc.get('sources_per_launch') == N else None
+    # (the traffic includes the interlaced image, 16 n^2 bytes per source, written on request of the caller --
+    #  align.py:684 always asks; bytes_per_displacement does not)
     return {
         'what': 'cc.find_displacement (cc.py:21-95) for a batch: 5 cutouts per source, NCC, interlaced image '
                 'written to HBM; same process, after the headline loop; NOT part of `value`',
         'value': rate, 'unit': 'displacements/s', 'cross_correlations_per_s': 4.0 * rate,
         'sources_per_launch': N, 'cutout': n, 'cc_type': 'NCC', 'steps': steps,
-        'kernel': 'spx::disp5_kernel<2, false, float>', 'kernel_ms': ms,
+        'kernel': 'spx::p5::disp5p_kernel<false, float>', 'kernel_ms': ms,
         'bytes_per_displacement': bytes_per,
         'achieved_GBps': rate * bytes_per / 1e9, 'frac_of_hbm_peak': rate * bytes_per / 1e9 / HBM_PEAK_GBS,
         'traffic': traffic, 'traffic_source': src if traffic is not None else None,

@@ -352,16 +352,17 @@ int run_disp5(DeviceTables* t, Tile tile, bool fold, const TIn* ref, const TIn* 
         return 0;
     }
     // 64 tile: the packed kernel (five transforms per source, one workgroup per CU: spx_kernels5.h) or the
-    // round-2 one (eight, two per CU).  Measured (profiles/r03/disp5_packed_ab*.txt): packed is 10 % faster for
-    // plain CC up to 64 px and slower where a second memory-bound pass runs uncovered on a CU with one workgroup
-    // (the statistics of NCC / ZNCC: -4 %) and on the fold path (-5 %): it takes plain CC up to 64 px.
+    // round-2 one (eight, two per CU).  Measured on one box, alternating (profiles/r03/disp5_rstd_and_packed_ab.txt,
+    // disp5_packed_ab_first.txt): up to 64 px packed is faster for plain CC (+10 %) and NCC (+7 %) and level for
+    // ZNCC (-1 %); on the fold path (65..85 px: a staged region twice the size, uncovered on a CU with one
+    // workgroup) it is 7-15 % slower.  It takes the cutouts up to 64 px.
     // SPX_DISP5_PACKED = 0 never | 1 that rule (default) | 2 always  (A/B knob, read once)
     static const int mode = [] {
         const char* e = getenv("SPX_DISP5_PACKED");
         const int v = e ? atoi(e) : SPX_DISP5_PACKED_DEFAULT;
         return v < 0 || v > 2 ? 1 : v;
     }();
-    const bool packed = mode == 2 || (mode == 1 && a.cc_type == 0 && !fold);
+    const bool packed = mode == 2 || (mode == 1 && !fold);
     {
         const int lds5 = fold ? spx::p5::L5<true>::TOTAL : spx::p5::L5<false>::TOTAL;
         auto k5 = fold ? spx::p5::disp5p_kernel<true, TIn> : spx::p5::disp5p_kernel<false, TIn>;

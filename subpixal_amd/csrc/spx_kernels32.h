@@ -64,7 +64,7 @@ SPX_DEVICE NormStatsT<TIn> norm_stats_wave(const TIn* __restrict__ ref, const TI
                                      int npool, int64_t im_stride, int npx, int cc_type) {
     NormStatsT<TIn> ns;
     ns.active = 0;
-    ns.im_mean = 0; ns.im_std = 1; ns.ref_mean = 0; ns.ref_std = 1;
+    ns.im_mean = 0; ns.im_rstd = 1; ns.ref_mean = 0; ns.ref_rstd = 1;
     if (cc_type == CC_PLAIN) return ns;
     const int lane = fresh_tid() & 63;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -91,9 +91,9 @@ SPX_DEVICE NormStatsT<TIn> norm_stats_wave(const TIn* __restrict__ ref, const TI
     ns.active = 1;
     const bool zero = (cc_type == CC_ZNCC);
     ns.im_mean = zero ? (TIn)im_mean : (TIn)0;
-    ns.im_std = (TIn)sqrt(b0 / a0);
+    ns.im_rstd = (TIn)(1.0 / sqrt(b0 / a0));
     ns.ref_mean = zero ? (TIn)ref_mean : (TIn)0;
-    ns.ref_std = (TIn)sqrt(b1 / a2);
+    ns.ref_rstd = (TIn)(1.0 / sqrt(b1 / a2));
     return ns;
 }
 
@@ -513,9 +513,9 @@ SPX_TKERNEL(256) void disp5_32_kernel(const TIn* __restrict__ ref, const TIn* __
         float* icc = icc_all + 4 * it.off;
         NormStatsT<TIn> ns = norm_stats_wave(r, m4, 4, stride, ny * nx, cc_type);
         ns.im_mean = rt::read_lane(ns.im_mean, 0);          // wave-uniform values -> scalar registers
-        ns.im_std = rt::read_lane(ns.im_std, 0);
+        ns.im_rstd = rt::read_lane(ns.im_rstd, 0);
         ns.ref_mean = rt::read_lane(ns.ref_mean, 0);
-        ns.ref_std = rt::read_lane(ns.ref_std, 0);
+        ns.ref_rstd = rt::read_lane(ns.ref_rstd, 0);
         float bv = -__builtin_inff();
         int bi = 0x7fffffff;
         for (int q = 0; q < 4; ++q) {

@@ -325,9 +325,9 @@ SPX_DEVICE void disp5p_body(const TIn* __restrict__ ref, const TIn* __restrict__
     const int64_t stride = (int64_t)ny * nx;
     NormStatsT<TIn> ns = norm_stats(scr, ref, im4, 4, stride, ny, nx, cc_type);
     ns.im_mean = rt::read_lane(ns.im_mean, 0);          // workgroup-uniform: scalar registers
-    ns.im_std = rt::read_lane(ns.im_std, 0);
+    ns.im_rstd = rt::read_lane(ns.im_rstd, 0);
     ns.ref_mean = rt::read_lane(ns.ref_mean, 0);
-    ns.ref_std = rt::read_lane(ns.ref_std, 0);
+    ns.ref_rstd = rt::read_lane(ns.ref_rstd, 0);
     ns.active = rt::read_lane(ns.active, 0);
 
     // R = FFT(ref), kept in registers for both dither pairs.  (Issuing a staging step's loads one step ahead --

@@ -122,7 +122,7 @@ SPX_DEVICE NormStatsT<TIn> norm_stats8(unsigned char* scr, const TIn* __restrict
                                        int ny, int nx, int cc_type) {
     NormStatsT<TIn> ns;
     ns.active = 0;
-    ns.im_mean = 0; ns.im_std = 1; ns.ref_mean = 0; ns.ref_std = 1;
+    ns.im_mean = 0; ns.im_rstd = 1; ns.ref_mean = 0; ns.ref_rstd = 1;
     if (cc_type == CC_PLAIN) return ns;
     const int tid = fresh_tid();
     const int npx = ny * nx;
@@ -162,9 +162,9 @@ SPX_DEVICE NormStatsT<TIn> norm_stats8(unsigned char* scr, const TIn* __restrict
     ns.active = 1;
     const bool zero = (cc_type == CC_ZNCC);
     ns.im_mean = zero ? (TIn)im_mean : (TIn)0;
-    ns.im_std = (TIn)sqrt(b0 / n_im);
+    ns.im_rstd = (TIn)(1.0 / sqrt(b0 / n_im));
     ns.ref_mean = zero ? (TIn)ref_mean : (TIn)0;
-    ns.ref_std = (TIn)sqrt(b1 / n_un);
+    ns.ref_rstd = (TIn)(1.0 / sqrt(b1 / n_un));
     return ns;
 }
 

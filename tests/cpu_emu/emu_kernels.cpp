@@ -189,8 +189,8 @@ extern "C" int emu_pair_f64(const double* ref, const double* img, int64_t nbatch
 #endif   // EMU_PART 1, 2
 
 #if EMU_PART == 3
-int g_disp5_packed = 1;          // 64-tile reference-mode kernel: 0 round 2's, 1 the product's rule (packed for plain CC
-                                 // up to 64 px: spx_capi.hip run_disp5), 2 always the packed one
+int g_disp5_packed = 1;          // 64-tile reference-mode kernel: 0 round 2's, 1 the product's rule (packed up to
+                                 // 64 px: spx_capi.hip run_disp5), 2 always the packed one
 extern "C" void emu_set_disp5_packed(int v) { g_disp5_packed = v; }
 // off/shp: per-item offsets and shapes (variable-shape batch of the family of (ny, nx)), or nulls
 template <typename TIn>
@@ -224,7 +224,7 @@ static int emu_disp5_t(const TIn* ref, const TIn* im4, int64_t nbatch, int ny, i
     if (n <= 85) {
         std::vector<float> tw = host::make_twiddles(128);
         const cf* twp = reinterpret_cast<const cf*>(tw.data());
-        if (g_disp5_packed == 2 || (g_disp5_packed == 1 && cc_type == 0 && n <= 64)) {        // spx_kernels5.h
+        if (g_disp5_packed == 2 || (g_disp5_packed == 1 && n <= 64)) {        // spx_kernels5.h
             if (n > 64)
                 rt::launch(nbatch, kThreads,
                            [&] { p5::disp5p_kernel<true, TIn>(ref, im4, nbatch, ny, nx, cc_type, twp, icc, out, status, items); },

@@ -40,7 +40,7 @@ def set_grid(g):
 
 def set_disp5_packed(v):
     """64-tile reference-mode kernel: 0 round 2's, 1 the product's rule (the five-transform kernel of
-    spx_kernels5.h for plain CC up to 64 px), 2 always the five-transform one"""
+    spx_kernels5.h up to 64 px, the eight-transform one on the fold path), 2 always the five-transform one"""
     lib().emu_set_disp5_packed(int(v))
 
 

@@ -144,8 +144,9 @@ print('five-transform kernel OK')
 
 def test_five_transform_reference_mode_kernel_for_every_cc_type(spx):
     """SPX_DISP5_PACKED=2 (read once per process, hence the child): spx_kernels5.h takes every 64-tile
-    reference-mode call -- NCC / ZNCC, float64 inputs, the fold path and ragged shapes too, not only the plain
-    CC it is the default for -- against the oracle's cc.find_displacement (cc.py:21-95)."""
+    reference-mode call -- the fold path (65..85 px) too, which the default dispatch leaves to the eight-transform
+    kernel -- for every cc_type, float64 inputs and ragged shapes, against the oracle's cc.find_displacement
+    (cc.py:21-95)."""
     env = dict(os.environ, SPX_DISP5_PACKED='2')
     out = subprocess.run([sys.executable, '-c', _PACKED_CHILD % {'root': ROOT}], env=env,
                          capture_output=True, text=True, timeout=900)

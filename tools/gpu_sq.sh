@@ -13,7 +13,9 @@ run() { # name counters...
 }
 run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT || exit 1
 run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS || exit 1
-# dynamic FLOP census: per-class VALU instruction counts + MFMA operations
-run sqf SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 || echo "FLOP counters not available on this build of rocprofv3"
+# dynamic FLOP census.  SQ_INSTS_VALU_FLOPS_FP32 counts per wave-instruction 2 for a scalar FMA,
+# 4 for v_pk_fma_f32, 2 for v_pk_add/mul_f32 (calibrated: tools/gpu_flop_calib.sh, profiles/r03/flop_counter_calibration.txt;
+# the per-class counters FMA/ADD/MUL_F32 count a packed instruction ONCE), MFMA_MOPS 512 FLOP each
+run sqf SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 || echo "FLOP counters not available on this build of rocprofv3"
 cd $GRAFT_REPO_ROOT
 python3 tools/sq_summary.py $TAG

@@ -31,17 +31,15 @@ if 'SQ_ACTIVE_INST_VALU' in m and 'SQ_WAVE_CYCLES' in m:
 if 'SQ_WAIT_ANY' in m and 'SQ_WAVE_CYCLES' in m:
     out['wait_any_fraction'] = m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']
     out['wait_inst_any_fraction'] = m.get('SQ_WAIT_INST_ANY', 0.0) / m['SQ_WAVE_CYCLES']
-if 'SQ_INSTS_VALU_FMA_F32' in m:
-    # one count per wave-instruction; a packed instruction does 2 operations per lane (counted as issued):
-    # FLOP = 64 lanes x (2 FMA + ADD + MUL + TRANS) for f32 and f64; MFMA_MOPS counts 512 FLOP each (guide: rocprof)
-    vec = 64.0 * (2 * m.get('SQ_INSTS_VALU_FMA_F32', 0) + m.get('SQ_INSTS_VALU_ADD_F32', 0) + m.get('SQ_INSTS_VALU_MUL_F32', 0)
-                  + m.get('SQ_INSTS_VALU_TRANS_F32', 0) + 2 * m.get('SQ_INSTS_VALU_FMA_F64', 0)
-                  + m.get('SQ_INSTS_VALU_ADD_F64', 0) + m.get('SQ_INSTS_VALU_MUL_F64', 0))
-    mat = 512.0 * m.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0)
+if 'SQ_INSTS_VALU_FLOPS_FP32' in m:
+    # FLOPS_FP32/FP64: FLOP per lane per wave-instruction, packed instructions counted at 2 operations per lane
+    # (calibrated, profiles/r03/flop_counter_calibration.txt) -> x 64 lanes; MFMA_MOPS: 512 FLOP each
+    vec = 64.0 * (m.get('SQ_INSTS_VALU_FLOPS_FP32', 0) + m.get('SQ_INSTS_VALU_FLOPS_FP64', 0))
+    mat = 512.0 * (m.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0) + m.get('SQ_INSTS_VALU_MFMA_MOPS_F64', 0))
     out.update({'vector_flop_per_pair': vec / a.pairs, 'matrix_flop_per_pair': mat / a.pairs,
                 'flop_per_pair': (vec + mat) / a.pairs,
-                'note': 'packed f32 instructions are counted once by the SQ class counters; see DESIGN.md section 5 for '
-                        'the calibration of these counters against the static census'})
+                'note': 'dynamic: 64 x (SQ_INSTS_VALU_FLOPS_FP32 + _FP64) + 512 x SQ_INSTS_VALU_MFMA_MOPS_F32/F64 of the bench '
+                        'kernel, per launch / pairs (lanes switched off by EXEC are counted as if active)'})
     json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'sq_flops_%d_u%d_%s.json' % (a.tile, a.upsample, a.tag)), 'w'), indent=1)
 json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'sq_summary_%s.json' % a.tag), 'w'), indent=1)
 print(json.dumps(out, indent=1))
