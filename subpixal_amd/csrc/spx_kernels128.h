@@ -116,10 +116,68 @@ SPX_DEVICE void stage_yfold_rows(unsigned char* lds, const TIn* __restrict__ ref
     }
 }
 
+// Full 128x128 float32 tiles (BASELINE config 3), 16-byte aligned: plain 16-byte loads, ALL 32 of a thread's
+// loads of the round in flight together (the general routine above keeps 16: its chunk records need twice
+// the registers) -- one exposed trip to memory per round instead of two.
+template <int C>
+SPX_DEVICE void stage_yfold_full128(unsigned char* lds, const float* __restrict__ ref,
+                                    const float* __restrict__ img, const NormStatsT<float>& ns, float bal,
+                                    int cy, float (&ssq)[2]) {
+    typedef LdsBig<C> L;
+    const int tid = fresh_tid();
+    float* ure = reinterpret_cast<float*>(lds + L::R_OFF);
+    float* uim = ure + 64 * kUS;
+    const float wr = cy == 0 ? 1.0f : (C == 4 ? (cy == 2 ? -1.0f : 0.0f) : -0.5f);
+    const float wi = cy == 0 ? 0.0f : (C == 4 ? (cy == 1 ? -1.0f : (cy == 3 ? 1.0f : 0.0f))
+                                              : (cy == 1 ? -0.86602540378443865f : 0.86602540378443865f));
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(ref);
+    const f32x4* m4 = reinterpret_cast<const f32x4*>(img);
+    f32x4 rt[8], rb[8], mt[8], mb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * kThreads;                 // 64 rows x 32 chunks
+        const int yl = idx >> 5, c = idx & 31;
+        rt[i] = r4[yl * 32 + c];
+        rb[i] = r4[(yl + 64) * 32 + c];
+        mt[i] = m4[(127 - yl) * 32 + (31 - c)];             // flip(img): row 127 - y, columns back to front
+        mb[i] = m4[(63 - yl) * 32 + (31 - c)];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * kThreads;
+        const int yl = idx >> 5, x = (idx & 31) << 2;
+        f32x4 ore, oim;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float tre = rt[i][e], bre = rb[i][e], tim = mt[i][3 - e], bim = mb[i][3 - e];
+            if (ns.active) {
+                tre = norm_ref(tre, ns); bre = norm_ref(bre, ns);
+                tim = norm_im(tim, ns); bim = norm_im(bim, ns);
+            }
+            if (cy == 0) {
+                ssq[0] += tre * tre + bre * bre;
+                ssq[1] += tim * tim + bim * bim;
+            }
+            const float ti = bal * tim, bi = bal * bim;
+            ore[e] = __builtin_fmaf(-wi, bi, __builtin_fmaf(wr, bre, tre));
+            oim[e] = __builtin_fmaf(wi, bre, __builtin_fmaf(wr, bi, ti));
+        }
+        *reinterpret_cast<f32x4*>(ure + yl * kUS + x) = ore;
+        *reinterpret_cast<f32x4*>(uim + yl * kUS + x) = oim;
+    }
+}
+
 template <int C, typename TIn>
 SPX_DEVICE void stage_yfold(unsigned char* lds, const TIn* __restrict__ ref,
                             const TIn* __restrict__ img, int ny, int nx,
                             const NormStatsT<TIn>& ns, float bal, int cy, float (&ssq)[2]) {
+    if constexpr (sizeof(TIn) == 4) {
+        if (ny == 128 && nx == 128 &&
+            ((reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(img)) & 15) == 0) {
+            stage_yfold_full128<C>(lds, ref, img, ns, bal, cy, ssq);
+            return;
+        }
+    }
     // cutouts narrower than a load chunk: element loads (chunk_issue), uniform per item
     if (nx < 4) stage_yfold_rows<C, TIn, true>(lds, ref, img, ny, nx, ns, bal, cy, ssq);
     else if ((nx & 3) == 0) stage_yfold_rows<C, TIn, false, true>(lds, ref, img, ny, nx, ns, bal, cy, ssq);

@@ -291,6 +291,24 @@ extern "C" int emu_gather(const float* frame, const uint8_t* fmask, int fny, int
     return 0;
 }
 
+extern "C" int emu_gather_var(const float* frame, const uint8_t* fmask, int fny, int fnx, const int32_t* boxes,
+                              int64_t nbatch, const int64_t* off, float fill, float* out, const int32_t* seg,
+                              const int32_t* ids) {
+    rt::launch(nbatch < 3 ? nbatch : 3, 256, [&] {
+        gather_cutouts_var_kernel(frame, fmask, fny, fnx, boxes, nbatch, off, fill, out, seg, ids);
+    }, 0);
+    return 0;
+}
+
+extern "C" int emu_blot4_var(const float* src, const int64_t* src_off, const int32_t* src_shp, int64_t nbatch,
+                             const double* map, int degree, const float* gain, const int64_t* dst_off,
+                             const int32_t* dst_shp, float* im4) {
+    rt::launch(nbatch < 3 ? nbatch : 3, 256, [&] {
+        blot4_var_kernel(src, src_off, src_shp, nbatch, map, degree, gain, dst_off, dst_shp, im4);
+    }, 0);
+    return 0;
+}
+
 extern "C" int emu_gen_pairs(uint64_t seed, int64_t first, int64_t nbatch, int n, float slo,
                              float shi, float maxshift, float* ref, float* img, double* truth) {
     rt::launch(nbatch, 256, [&] {

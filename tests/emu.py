@@ -187,3 +187,44 @@ def gen_pairs(seed, first, count, n, slo, shi, maxshift):
                              _p(ref, _fp), _p(img, _fp), _p(truth, _dp))
     assert rc == 0
     return ref, img, truth
+
+
+def gather_var(frame, fmask, boxes, fill, seg=None, ids=None):
+    """variable-shape gather: returns (packed float32, offsets int64)"""
+    frame = np.ascontiguousarray(frame, np.float32)
+    boxes = np.ascontiguousarray(boxes, np.int32)
+    sizes = boxes[:, 2].astype(np.int64) * boxes[:, 3]
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    out = np.full(int(sizes.sum()), -7.0, np.float32)
+    i32, i64 = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
+    if fmask is not None:
+        fmask = np.ascontiguousarray(fmask, np.uint8)
+    seg_a = None if seg is None else np.ascontiguousarray(seg, np.int32)
+    ids_a = None if ids is None else np.ascontiguousarray(ids, np.int32)
+    rc = lib().emu_gather_var(_p(frame, _fp), _p(fmask, _bp), frame.shape[0], frame.shape[1], boxes.ctypes.data_as(i32),
+                              ctypes.c_int64(len(boxes)), offs.ctypes.data_as(i64), ctypes.c_float(fill), _p(out, _fp),
+                              None if seg_a is None else seg_a.ctypes.data_as(i32),
+                              None if ids_a is None else ids_a.ctypes.data_as(i32))
+    assert rc == 0
+    return out, offs
+
+
+def blot4_var(src, src_offs, src_shapes, maps, degree, dst_shapes, gain=None):
+    """variable-shape blots: returns (im4 packed float32, dst offsets)"""
+    src = np.ascontiguousarray(src, np.float32)
+    src_offs = np.ascontiguousarray(src_offs, np.int64)
+    src_shapes = np.ascontiguousarray(src_shapes, np.int32)
+    dst_shapes = np.ascontiguousarray(dst_shapes, np.int32)
+    maps = np.ascontiguousarray(maps, np.float64)
+    sizes = dst_shapes[:, 0].astype(np.int64) * dst_shapes[:, 1]
+    doffs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    im4 = np.full(4 * int(sizes.sum()), -7.0, np.float32)
+    if gain is not None:
+        gain = np.ascontiguousarray(gain, np.float32)
+    i32, i64 = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
+    rc = lib().emu_blot4_var(_p(src, _fp), src_offs.ctypes.data_as(i64), src_shapes.ctypes.data_as(i32),
+                             ctypes.c_int64(len(src_offs)), maps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                             int(degree), _p(gain, _fp), doffs.ctypes.data_as(i64), dst_shapes.ctypes.data_as(i32),
+                             _p(im4, _fp))
+    assert rc == 0
+    return im4, doffs

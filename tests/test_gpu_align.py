@@ -202,3 +202,59 @@ def test_catalog_sequence_semantics_and_errors():
         find_linear_fit(cat, CutoutCatalog(frame, boxes[:1]), affine=blot.shift_affine(2))
     with pytest.raises(ValueError, match="positive"):
         pack_cutouts_var(frame, np.array([[0, 0, 0, 4]], np.int32))
+
+
+def test_catalog_path_every_family_general_path_poly_maps_and_bad_sources():
+    """the catalog path's other branches: a source of every kernel family (32 / 64 / fold / period 192) plus one
+    above 128 px (general path, one launch per shape from the packed buffers), polynomial maps, a NaN pixel and a
+    2-pixel-wide cutout -- each source bit-identical to cc.find_displacement on its own Cutout objects"""
+    import torch
+    from subpixal_amd import blot, cc
+    from subpixal_amd.align import find_linear_fit, ST_SKIPPED
+    from subpixal_amd.cutout import CutoutCatalog
+    rng = np.random.default_rng(6)
+    size = 700
+    xy = np.array([[80, 90], [200, 120], [350, 140], [520, 160], [200, 450], [480, 480], [620, 60]], np.float64) + rng.uniform(-0.4, 0.4, (7, 2))
+    wh = np.array([[30, 20], [44, 40], [66, 70], [90, 100], [150, 140], [40, 40], [2, 30]])
+    t = np.array([0.6, -0.9])
+    drz = np.zeros((size, size), np.float32)
+    img = np.zeros((size, size), np.float32)
+    yy, xx = np.mgrid[:size, :size].astype(np.float64)
+    for k, (x, y) in enumerate(xy):
+        s = 2.5 + 0.8 * k
+        drz += np.exp(-((xx - x) ** 2 + (yy - y) ** 2) / (2 * s * s)).astype(np.float32)
+        img += np.exp(-((xx - x - t[0]) ** 2 + (yy - y - t[1]) ** 2) / (2 * s * s)).astype(np.float32)
+    img[int(xy[5, 1]), int(xy[5, 0])] = np.nan                              # source 5: non-finite -> status 6
+    boxes = np.stack([np.round(xy[:, 0]).astype(int) - wh[:, 0] // 2, np.round(xy[:, 1]).astype(int) - wh[:, 1] // 2,
+                      wh[:, 0], wh[:, 1]], axis=1).astype(np.int32)
+    m = 8
+    dboxes = boxes + np.array([-m, -m, 2 * m, 2 * m], np.int32)
+    img_cat = CutoutCatalog(img, boxes, src_pos=xy + t)
+    drz_cat = CutoutCatalog(drz, dboxes, src_pos=xy, src_weight=np.ones(7))
+    aff = blot.shift_affine(7, x0=float(m), y0=float(m))
+    fit, iccs, blts = find_linear_fit(img_cat, drz_cat, affine=aff, fitgeom='shift', cc_type='NCC')
+    d, st = fit['subpixal_img_dxy'], fit['subpixal_status']
+    assert list(st) == [0, 0, 0, 0, 0, 6, ST_SKIPPED]
+    assert not fit['fitmask'][5] and not fit['fitmask'][6] and fit['fitmask'][:5].all()
+    np.testing.assert_allclose(d[:5], np.tile(-t, (5, 1)), atol=5e-3)
+    np.testing.assert_allclose(fit['offset'], -t, atol=3e-3)
+    for k in range(6):
+        imct, dzct = img_cat[k], drz_cat[k]
+        dzct.data[dzct.mask] = 0
+        b = blot.blot_affine4_batch(dzct.data[None], aff[k:k + 1], imct.data.shape)[0]
+        dx, dy, icc, _ = cc.find_displacement(imct.data, b[0], b[1], b[2], b[3], cc_type='NCC', full_output=True)
+        if k == 5:
+            assert not (np.isfinite(dx) and np.isfinite(dy)) or (dx, dy) == (d[k, 0], d[k, 1])
+        else:
+            assert dx == d[k, 0] and dy == d[k, 1], k
+            assert np.array_equal(icc, iccs[k]) and np.array_equal(b[0], blts[k])
+    # the same maps as degree-2 polynomials (u, v relative to the cutout centre): xs = u + (nx-1)/2 + m, ...
+    coef = np.zeros((7, 2, 21))
+    for k in range(7):
+        coef[k, 0, 0] = (wh[k, 0] - 1) / 2.0 + m
+        coef[k, 1, 0] = (wh[k, 1] - 1) / 2.0 + m
+        coef[k, 0, 1] = 1.0          # u
+        coef[k, 1, 2] = 1.0          # v
+    fit2, _, _ = find_linear_fit(img_cat, drz_cat, poly=(coef, 2), fitgeom='shift', cc_type='NCC')
+    np.testing.assert_allclose(fit2['subpixal_img_dxy'][:5], d[:5], atol=2e-5)
+    assert list(fit2['subpixal_status']) == list(st)

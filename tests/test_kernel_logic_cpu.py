@@ -523,3 +523,46 @@ def test_cutouts_narrower_than_a_load_chunk():
     t = datagen.dither_set(130, 3, 0.2, -0.3, 0.9, 1.0, np.float32)           # general path
     d, st, _ = emu.disp5(t[0][None], np.stack(t[1:])[None], 1)
     assert np.abs(d[0] - np.array(orc.find_displacement(*t, cc_type='NCC'))).max() < 2e-5
+
+
+def test_catalog_gather_and_blots_equal_the_fixed_shape_kernels():
+    """round 3: gather_cutouts_var_kernel / blot4_var_kernel (packed variable-shape catalog) against the
+    fixed-shape kernels they generalise, item by item, bit for bit; boxes overhanging the frame, masks, segments,
+    affine and polynomial maps, gains, a source too small to resample"""
+    rng = np.random.default_rng(12)
+    frame = rng.standard_normal((90, 110)).astype(np.float32)
+    frame[20, 30] = np.inf
+    fmask = rng.random((90, 110)) < 0.02
+    seg = (rng.random((90, 110)) < 0.5).astype(np.int32) * 3
+    boxes = np.array([[10, 12, 33, 21], [-4, 70, 20, 30], [60, 5, 7, 9], [100, 80, 15, 14], [40, 40, 5, 64]], np.int32)
+    ids = np.array([3, 3, 0, 3, 3], np.int32)
+    packed, offs = emu.gather_var(frame, fmask, boxes, 0.0, seg, ids)
+    for k, (x0, y0, w, h) in enumerate(boxes):
+        want = emu.gather(frame, fmask, boxes[k:k + 1], int(h), int(w), 0.0, seg, ids[k:k + 1])[0]
+        assert np.array_equal(packed[offs[k]:offs[k] + w * h].reshape(h, w), want), k
+    raw, _ = emu.gather_var(frame, None, boxes, np.nan)
+    assert np.isnan(raw[offs[1]]) and not np.any(raw == -7.0)
+    # blots: sources = the packed cutouts above, targets of other shapes
+    src_shapes = boxes[:, [3, 2]]
+    dst_shapes = np.array([[20, 25], [12, 31], [8, 8], [9, 10], [40, 6]], np.int32)
+    aff = np.stack([np.array([1.01, 0.02, 2.3, -0.01, 0.98, 1.7]) for _ in range(5)])
+    aff[:, 2] += np.arange(5) * 0.37
+    gain = np.array([1.0, 0.5, 2.0, 1.5, 3.0], np.float32)
+    src = np.where(np.isfinite(packed), packed, 0.0).astype(np.float32)
+    im4, doffs = emu.blot4_var(src, offs, src_shapes, aff, 0, dst_shapes, gain)
+    coef = np.zeros((5, 2, 21))
+    coef[:, 0, 0], coef[:, 1, 0] = 3.0, 2.5
+    coef[:, 0, 1], coef[:, 1, 2] = 0.97, 1.02
+    coef[:, 0, 4] = 1e-3
+    im4p, _ = emu.blot4_var(src, offs, src_shapes, coef, 3, dst_shapes)
+    for k in range(5):
+        h, w = (int(v) for v in src_shapes[k])
+        ny, nx = (int(v) for v in dst_shapes[k])
+        tile = src[offs[k]:offs[k] + h * w].reshape(1, h, w)
+        got = im4[4 * doffs[k]:4 * doffs[k] + 4 * ny * nx].reshape(4, ny, nx)
+        gotp = im4p[4 * doffs[k]:4 * doffs[k] + 4 * ny * nx].reshape(4, ny, nx)
+        if min(h, w) < 6:                          # too small for the quintic: no signal
+            assert not got.any() and not gotp.any()
+            continue
+        assert np.array_equal(got, emu.blot_affine4(tile, aff[k:k + 1], ny, nx, gain[k:k + 1])[0]), k
+        assert np.array_equal(gotp, emu.blot_poly4(tile, coef[k:k + 1], 3, ny, nx)[0]), k

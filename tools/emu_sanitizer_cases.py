@@ -65,4 +65,27 @@ for n in (24, 48) if quick else (24, 48, 77, 100, 140):
     e, est = orc.find_displacement_batch(r, m4, 'NCC')
     print('find_displacement %3dx%-3d max |d| %.2e' % (n, n, float(np.abs(d - e).max())), flush=True)
     assert np.abs(d - e).max() < 1e-4
+# round 3: the eight-wave pair kernel (spx_kernels8.h) and the five-transform reference-mode kernel
+# (spx_kernels5.h), several items per workgroup
+ref, img, truth = datagen.pair_batch(11, 5, 64)
+for up in (1, 10) if quick else (1, 10, 20, 43):
+    emu.set_grid(2)
+    try:
+        got, st = emu.pair(ref, img, up, tile=648)
+    finally:
+        emu.set_grid(0)
+    exp, est = orc.xcorr_refine_batch(ref, img, up)
+    print('eight-wave pair 64x64 U=%-2d max |d| %.2e' % (up, float(np.abs(got - exp).max())), flush=True)
+    assert np.array_equal(st, est) and np.abs(got - exp).max() < 1e-3
+emu.set_disp5_packed(2)
+try:
+    for n in (48,) if quick else (48, 64, 77, 85):
+        r, m4, t = datagen.dither_batch(5, 3, n)
+        for cc, name in ((0, 'CC'), (2, 'ZNCC')):
+            d, st, icc = emu.disp5(r, m4, cc)
+            e, est = orc.find_displacement_batch(r, m4, name)
+            print('five-transform find_displacement %3dx%-3d %s max |d| %.2e' % (n, n, name, float(np.abs(d - e).max())), flush=True)
+            assert np.array_equal(st, est) and np.abs(d - e).max() < 1e-4
+finally:
+    emu.set_disp5_packed(1)
 print('sanitizer cases OK')
