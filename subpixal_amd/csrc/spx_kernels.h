@@ -147,6 +147,27 @@ template <int DIR> SPX_DEVICE void fft8_x(cf (&v)[8][8]) {
     for (int y = 0; y < 8; ++y) fft8<DIR>(v[y]);
 }
 
+// one row / one column of the tile times w (CONJ: times conj(w)), in place
+#ifndef SPX_CMUL_BATCH
+#define SPX_CMUL_BATCH 1
+#endif
+template <bool CONJ> SPX_DEVICE void mul_row(cf (&v)[8][8], int y, cf w) {
+    if constexpr (SPX_CMUL_BATCH) {
+        rt::cmul8_ip<CONJ>(v[y][0], v[y][1], v[y][2], v[y][3], v[y][4], v[y][5], v[y][6], v[y][7], w);
+    } else {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) { if (CONJ) rt::cmulc_ip(v[y][x], w); else rt::cmul_ip(v[y][x], w); }
+    }
+}
+template <bool CONJ> SPX_DEVICE void mul_col(cf (&v)[8][8], int x, cf w) {
+    if constexpr (SPX_CMUL_BATCH) {
+        rt::cmul8_ip<CONJ>(v[0][x], v[1][x], v[2][x], v[3][x], v[4][x], v[5][x], v[6][x], v[7][x], w);
+    } else {
+#pragma unroll
+        for (int y = 0; y < 8; ++y) { if (CONJ) rt::cmulc_ip(v[y][x], w); else rt::cmul_ip(v[y][x], w); }
+    }
+}
+
 // lane <-> register transposition of an 8x8 complex tile through the wave's own LDS
 // buffer (64 rows of XS floats): (lane L, register R) -> (lane R, register L); real and
 // imaginary parts in two passes (ds_write2_b32 / ds_read_b128, conflict-free at XS = 68).
@@ -164,6 +185,63 @@ template <int XS> SPX_DEVICE void transpose_tile(cf (&v)[8][8], float* xch, int 
         }
         rt::wave_sync();
     }
+}
+
+// The same two passes with 4-byte reads (rt::lds_read_f32: never merged into ds_read_b128): a 16-byte
+// read lands in four consecutive registers, i.e. in the .x / .y slots of TWO elements, and every value
+// then needs a v_mov into its own (re, im) pair -- 64 vector moves per pass on the unit that bounds
+// the kernel; 4-byte reads land where they are used and cost LDS issue slots instead.
+template <int XS> SPX_DEVICE void transpose_tile_v(cf (&v)[8][8], float* xch, int lane) {
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int r = 0; r < 64; ++r)
+            xch[r * XS + lane] = part ? v[r >> 3][r & 7].y : v[r >> 3][r & 7].x;
+        rt::wave_sync();
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            const float t = rt::lds_read_f32(xch + lane * XS + r);
+            if (part) v[r >> 3][r & 7].y = t; else v[r >> 3][r & 7].x = t;
+        }
+        rt::wave_sync();
+    }
+}
+
+// Whole complex elements with the passes split by SOURCE lane half: in pass h the lanes of half h write
+// their 64 registers as (re, im) slots (row R, slot lane & 31: ds_write_b64, 256 contiguous bytes per
+// row), then ALL lanes read the 32 slots of their row with 16 ds_read_b128 -- two elements per read,
+// in place.  Half-wave writes instead of transpose_tile_cplx's half-wave reads, no moves either.
+template <int XS> SPX_DEVICE void transpose_tile_w(cf (&v)[8][8], float* xch, int lane) {
+    static_assert(XS >= 68 && (XS & 3) == 0, "32 complex slots per row plus the conflict padding");
+    cf* buf = reinterpret_cast<cf*>(xch);
+    cf t[64];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if ((lane >> 5) == h) {
+#pragma unroll
+            for (int r = 0; r < 64; ++r) buf[r * (XS / 2) + (lane & 31)] = v[r >> 3][r & 7];
+        }
+        rt::wave_sync();
+        const f32x4* row = reinterpret_cast<const f32x4*>(buf + lane * (XS / 2));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const f32x4 q = row[j];
+            t[32 * h + 2 * j] = cf{q[0], q[1]};
+            t[32 * h + 2 * j + 1] = cf{q[2], q[3]};
+        }
+        rt::wave_sync();
+    }
+#pragma unroll
+    for (int r = 0; r < 64; ++r) v[r >> 3][r & 7] = t[r];
+}
+
+#ifndef SPX_TRANSPOSE_VARIANT
+#define SPX_TRANSPOSE_VARIANT 0
+#endif
+template <int XS> SPX_DEVICE void transpose_tile_sel(cf (&v)[8][8], float* xch, int lane) {
+    if constexpr (SPX_TRANSPOSE_VARIANT == 1) transpose_tile_v<XS>(v, xch, lane);
+    else if constexpr (SPX_TRANSPOSE_VARIANT == 2) transpose_tile_w<XS>(v, xch, lane);
+    else transpose_tile<XS>(v, xch, lane);
 }
 
 // A class plane on its way from the tile registers to 16-byte row-contiguous stores goes through the
@@ -723,6 +801,120 @@ SPX_DEVICE float balance_factor(unsigned char* lds_scr, float (&ssq)[2]) {
 // columns contiguous (16-byte reads stay aligned), and costs two integer ops.
 SPX_DEVICE int plane_col(int row, int col) { return col ^ (((row & 1) << 4) | ((row & 2) << 2)); }
 
+// ---------------------------------------------------------------------------
+// Structure-of-arrays operands (rt::bcast_mul / rt::bcast_fma_rot): element K (0..3) of a 16-byte
+// read `re4` of real parts and `im4` of imaginary parts, times w -- two packed instructions, and the
+// result is the (re, im) pair the butterflies want.  Wherever a multiply follows such a read anyway
+// (class twiddle after the tile load, stage twiddle after the transposition) this replaces the
+// moves that used to build the pair first (~190 of a wave's ~1350 non-arithmetic vector
+// instructions per pair).
+// ---------------------------------------------------------------------------
+// MEASURED AND NOT ADOPTED (SPX_FUSED_TW = 0 is the shipped path; -DSPX_FUSED_TW=1 builds the variant;
+// profiles/r03/variants_b1t0_fused.txt, sq_summary_fused.json): 8.5 % fewer vector instructions per pair
+// (16.3k -> 14.9k), the same 3.92 ms per 1e5 pairs -- the time went into waits instead (SQ_WAIT_INST_LDS
+// +83 %, ten spilled registers around the transposition).  The 64-tile kernel is not bound by the number
+// of vector instructions it issues.
+#ifndef SPX_FUSED_TW
+#define SPX_FUSED_TW 0
+#endif
+template <int K> SPX_DEVICE f32x2 quad_pair(f32x4 q) {
+    if constexpr (K < 2) return f32x2{q[0], q[1]}; else return f32x2{q[2], q[3]};
+}
+// (re4[K] + i im4[K]) w        (CONJ: conj(w))
+template <int K, bool CONJ> SPX_DEVICE cf soa_cmul_k(f32x4 re4, f32x4 im4, cf w) {
+    return rt::bcast_fma_rot<(K & 1), CONJ>(quad_pair<K>(im4), w, rt::bcast_mul<(K & 1), CONJ>(quad_pair<K>(re4), w));
+}
+template <bool CONJ> SPX_DEVICE cf soa_cmul(int k, f32x4 re4, f32x4 im4, cf w) {
+    switch (k & 3) {                      // k is a constant after unrolling
+        case 0: return soa_cmul_k<0, CONJ>(re4, im4, w);
+        case 1: return soa_cmul_k<1, CONJ>(re4, im4, w);
+        case 2: return soa_cmul_k<2, CONJ>(re4, im4, w);
+        default: return soa_cmul_k<3, CONJ>(re4, im4, w);
+    }
+}
+// re4[K] w + i im4[K] bw: the staged operand (re, bal im) times w with bw = bal w
+template <int K> SPX_DEVICE cf soa_cmul2_k(f32x4 re4, f32x4 im4, cf w, cf bw) {
+    return rt::bcast_fma_rot<(K & 1), false>(quad_pair<K>(im4), bw, rt::bcast_mul<(K & 1), false>(quad_pair<K>(re4), w));
+}
+SPX_DEVICE cf soa_cmul2(int k, f32x4 re4, f32x4 im4, cf w, cf bw) {
+    switch (k & 3) {
+        case 0: return soa_cmul2_k<0>(re4, im4, w, bw);
+        case 1: return soa_cmul2_k<1>(re4, im4, w, bw);
+        case 2: return soa_cmul2_k<2>(re4, im4, w, bw);
+        default: return soa_cmul2_k<3>(re4, im4, w, bw);
+    }
+}
+
+// The lane <-> register transposition (transpose_tile) with the reads left in structure-of-arrays
+// form and the twiddles of the register's second digit applied on the way out:
+//   v'[a][b] = T(v)[a][b] * w[b]      (CONJ: conj(w[b]);  W0_ONE: w[0] = 1, column 0 is only re-paired)
+template <int XS, bool CONJ, bool W0_ONE>
+SPX_DEVICE void transpose_tile_tw(cf (&v)[8][8], float* xch, int lane, const cf (&w)[8]) {
+    f32x4 re4[16], im4[16];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int r = 0; r < 64; ++r)
+            xch[r * XS + lane] = part ? v[r >> 3][r & 7].y : v[r >> 3][r & 7].x;
+        rt::wave_sync();
+        const f32x4* row = reinterpret_cast<const f32x4*>(xch + lane * XS);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { if (part) im4[j] = row[j]; else re4[j] = row[j]; }
+        rt::wave_sync();
+    }
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+        const int b = r & 7;
+        if (W0_ONE && b == 0) v[r >> 3][b] = cf{re4[r >> 2][r & 3], im4[r >> 2][r & 3]};
+        else v[r >> 3][b] = soa_cmul<CONJ>(r, re4[r >> 2], im4[r >> 2], w[b]);
+    }
+}
+
+// Tile load of the 64 tile with the class pre-twiddle w_P^{8 (CY y1 + CX x1)} (the free radix-2 stage
+// of the zero pad; wave-uniform values) folded into the step that pairs the staged real and imaginary
+// parts: v[y1][x1] = (re + i bal im) W_k, k = CY y1 + CX x1.  Class (1,1) used to pay 112 complex
+// multiplies on top of the pairing moves; now every class costs the same two instructions per element.
+template <typename G, int CY, int CX>
+SPX_DEVICE void load_tile_class(cf (&v)[8][8], const float* zre, const float* zim, const cf* tw, float bal,
+                                int l1, int l0) {
+    constexpr int NK = 7 * (CY + CX) + 1;
+    cf W[NK], BW[NK];
+#pragma unroll
+    for (int k = 1; k < NK; ++k) { W[k] = tw[8 * k]; BW[k] = cf{bal * W[k].x, bal * W[k].y}; }
+#pragma unroll
+    for (int y1 = 0; y1 < 8; ++y1) {
+        const f32x4* pr = reinterpret_cast<const f32x4*>(zre + (l1 + 8 * y1) * G::ZS + l0 * G::PS12);
+        const f32x4* pi = reinterpret_cast<const f32x4*>(zim + (l1 + 8 * y1) * G::ZS + l0 * G::PS12);
+        const f32x4 r0 = pr[0], r1 = pr[1], i0 = pi[0], i1 = pi[1];
+#pragma unroll
+        for (int x1 = 0; x1 < 8; ++x1) {
+            const int k = CY * y1 + CX * x1;
+            const f32x4 rq = x1 < 4 ? r0 : r1, iq = x1 < 4 ? i0 : i1;
+            if (k == 0) v[y1][x1] = cf{rq[x1 & 3], bal * iq[x1 & 3]};
+            else v[y1][x1] = soa_cmul2(x1, rq, iq, W[k], BW[k]);
+        }
+    }
+}
+
+// The class plane: Im(v conj(W_k)) with the class post-twiddle W_k = w_P^{8 (CY y1 + CX x1)} (wave-uniform
+// values: one multiply and one fused multiply-add per element; nothing at all for class (0,0)).
+template <typename L, int CY, int CX>
+SPX_DEVICE void store_plane_class(const cf (&v)[8][8], float* plane, const cf* tw, int l1, int l0) {
+    constexpr int NK = 7 * (CY + CX) + 1;
+    cf W[NK];
+#pragma unroll
+    for (int k = 1; k < NK; ++k) W[k] = tw[8 * k];
+#pragma unroll
+    for (int x1 = 0; x1 < 8; ++x1)
+#pragma unroll
+        for (int y1 = 0; y1 < 8; ++y1) {
+            const cf a = v[y1][x1];
+            const int k = CY * y1 + CX * x1;
+            const int row = l1 + 8 * y1;
+            plane[row * L::PS + plane_col(row, l0 + 8 * x1)] = k == 0 ? a.y : a.y * W[k].x - a.x * W[k].y;
+        }
+}
+
 // Diagnostic early exit for phase timing (tools/phase_timing.py, `make diag`): DBG
 // is a template parameter, 0 in the product library, so production code carries none
 // of it.  A stopped variant folds its registers into one float per lane and stores
@@ -770,7 +962,13 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
     // FOLD: the class's radix-2 fold of the samples beyond index 63 (they exist for
     // y, x < 24 only: the cutout ends before 88)
     const float fsx = cx ? -1.0f : 1.0f, fsy = cy ? -1.0f : 1.0f;
-    if constexpr (!FOLD) {
+    if constexpr (!FOLD && SPX_FUSED_TW) {
+        if (wave == 0) load_tile_class<G, 0, 0>(v, zre, zim, tw, bal, l1, l0);
+        else if (wave == 1) load_tile_class<G, 0, 1>(v, zre, zim, tw, bal, l1, l0);
+        else if (wave == 2) load_tile_class<G, 1, 0>(v, zre, zim, tw, bal, l1, l0);
+        else load_tile_class<G, 1, 1>(v, zre, zim, tw, bal, l1, l0);
+    }
+    if constexpr (!FOLD && !SPX_FUSED_TW) {
         // permuted rows (StageGeom): the lane's eight samples of a row are 32 contiguous bytes per plane
 #pragma unroll
         for (int y1 = 0; y1 < 8; ++y1) {
@@ -811,21 +1009,19 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
     clk.tick(1);
     rt::set_prio<0>();                          // the transforms are throughput work
 
-    // class pre-twiddle w_P^{c (8 y1)} (the free radix-2 stage of the zero pad)
-    if (cy) {
+    // class pre-twiddle w_P^{c (8 y1)} (the free radix-2 stage of the zero pad; the 64 tile's load has it)
+    if (cy && (FOLD || !SPX_FUSED_TW)) {
 #pragma unroll
         for (int y1 = 1; y1 < 8; ++y1) {
             const cf w = tw[8 * cy * y1];
-#pragma unroll
-            for (int x1 = 0; x1 < 8; ++x1) rt::cmul_ip(v[y1][x1], w);
+            mul_row<false>(v, y1, w);
         }
     }
-    if (cx) {
+    if (cx && (FOLD || !SPX_FUSED_TW)) {
 #pragma unroll
         for (int x1 = 1; x1 < 8; ++x1) {
             const cf w = tw[8 * cx * x1];
-#pragma unroll
-            for (int y1 = 0; y1 < 8; ++y1) rt::cmul_ip(v[y1][x1], w);
+            mul_col<false>(v, x1, w);
         }
     }
     fft8_y<1>(v);                           // y1 -> kyb
@@ -839,17 +1035,28 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[kb][j] = cmul(v[kb][j], wy);
     }
+    if constexpr (!SPX_FUSED_TW) {
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-        const cf wx = tw[l0 * (cx + C * kb)];
+        for (int kb = 0; kb < 8; ++kb) {
+            const cf wx = tw[l0 * (cx + C * kb)];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j][kb] = cmul(v[j][kb], wx);
+            for (int j = 0; j < 8; ++j) v[j][kb] = cmul(v[j][kb], wx);
+        }
     }
 
     SPX_DBG_STOP(3);
     clk.tick(3);
     // ---- transposition: (lane (y0,x0), reg (kyb,kxb)) -> (lane (kyb,kxb), reg (y0,x0))
-    transpose_tile<L::XS>(v, xch, lane);
+    if constexpr (SPX_FUSED_TW) {
+        // ... and the x twiddle on the way out: there the lane holds kxb (= l0) and the register x0
+        cf wxa[8];
+#pragma unroll
+        for (int x0 = 1; x0 < 8; ++x0) wxa[x0] = tw[x0 * (cx + C * l0)];
+        wxa[0] = cf{1.0f, 0.0f};
+        transpose_tile_tw<L::XS, false, true>(v, xch, lane, wxa);
+    } else {
+        transpose_tile_sel<L::XS>(v, xch, lane);
+    }
 
     SPX_DBG_STOP(4);
     clk.tick(4);
@@ -879,16 +1086,26 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[y0][j] = cmulc(v[y0][j], wy);
     }
+    if constexpr (!SPX_FUSED_TW) {
 #pragma unroll
-    for (int x0 = 1; x0 < 8; ++x0) {          // x0 = 0: w^0
-        const cf wx = tw[x0 * (cx + C * l0)];
+        for (int x0 = 1; x0 < 8; ++x0) {          // x0 = 0: w^0
+            const cf wx = tw[x0 * (cx + C * l0)];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j][x0] = cmulc(v[j][x0], wx);
+            for (int j = 0; j < 8; ++j) v[j][x0] = cmulc(v[j][x0], wx);
+        }
     }
     SPX_DBG_STOP(7);
     clk.tick(7);
     // ---- transposition back: -> lane (y0, x0), registers (kyb, kxb)
-    transpose_tile<L::XS>(v, xch, lane);
+    if constexpr (SPX_FUSED_TW) {
+        // ... with the x twiddle on the way out: the lane holds x0 (= l0) and the register kxb
+        cf wxb[8];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) wxb[kb] = tw[l0 * (cx + C * kb)];
+        transpose_tile_tw<L::XS, true, false>(v, xch, lane, wxb);
+    } else {
+        transpose_tile_sel<L::XS>(v, xch, lane);
+    }
     SPX_DBG_STOP(8);
     clk.tick(8);
     // ---- inverse round B': registers (kyb, kxb) -> (y1, x1)
@@ -901,12 +1118,17 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
     // 1/2 of conv = Im(IFFT(Z^2))/2 is folded into the readers' output scale).
     // The plane goes into this wave's own exchange buffer (its reads above are done).
     float* plane = reinterpret_cast<float*>(lds + L::R_OFF + wave * L::PLANE_STRIDE_BYTES);
+    if constexpr (SPX_FUSED_TW) {
+        if (wave == 0) store_plane_class<L, 0, 0>(v, plane, tw, l1, l0);
+        else if (wave == 1) store_plane_class<L, 0, 1>(v, plane, tw, l1, l0);
+        else if (wave == 2) store_plane_class<L, 1, 0>(v, plane, tw, l1, l0);
+        else store_plane_class<L, 1, 1>(v, plane, tw, l1, l0);
+    } else {
     if (cy) {
 #pragma unroll
         for (int y1 = 1; y1 < 8; ++y1) {
             const cf wy = tw[8 * cy * y1];
-#pragma unroll
-            for (int x1 = 0; x1 < 8; ++x1) rt::cmulc_ip(v[y1][x1], wy);
+            mul_row<true>(v, y1, wy);
         }
     }
 #pragma unroll
@@ -918,6 +1140,7 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
             const int row = l1 + 8 * y1;
             plane[row * L::PS + plane_col(row, l0 + 8 * x1)] = a.y * wx.x - a.x * wx.y;      // Im(a conj w)
         }
+    }
     }
     rt::block_sync_lds();
     clk.tick(10);

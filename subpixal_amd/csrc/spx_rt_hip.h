@@ -129,6 +129,58 @@ SPX_DEVICE void cmulc_ip(f32x2& a, f32x2 w) {
         "v_pk_fma_f32 %0, %0, %2, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
         : "+v"(a), "=&v"(t) : "v"(w));
 }
+// eight in-place multiplies by one w as ONE asm block with two alternating scratch pairs.  Between
+// two single-element blocks that were given the same scratch pair the compiler inserts an s_nop (its
+// conservative rule for a register written by one inline-asm block and touched by the next: it cannot
+// see that the writer is not a partial-register write); inside a block there is nothing to protect.
+template <bool CONJ>
+SPX_DEVICE void cmul8_ip(f32x2& a0, f32x2& a1, f32x2& a2, f32x2& a3, f32x2& a4, f32x2& a5, f32x2& a6, f32x2& a7,
+                         f32x2 w) {
+    f32x2 t0, t1;
+#define SPX_CM_MUL(T, A) "v_pk_mul_f32 " T ", " A ", %10 op_sel_hi:[1,0]\n\t"
+#define SPX_CM_FMA(T, A, NEG) "v_pk_fma_f32 " A ", " A ", %10, " T " op_sel:[1,1,0] op_sel_hi:[0,1,1] " NEG ":[1,0,0]\n\t"
+#define SPX_CM_BODY(NEG)                                                                                     \
+    SPX_CM_MUL("%8", "%0") SPX_CM_MUL("%9", "%1") SPX_CM_FMA("%8", "%0", NEG) SPX_CM_FMA("%9", "%1", NEG)    \
+    SPX_CM_MUL("%8", "%2") SPX_CM_MUL("%9", "%3") SPX_CM_FMA("%8", "%2", NEG) SPX_CM_FMA("%9", "%3", NEG)    \
+    SPX_CM_MUL("%8", "%4") SPX_CM_MUL("%9", "%5") SPX_CM_FMA("%8", "%4", NEG) SPX_CM_FMA("%9", "%5", NEG)    \
+    SPX_CM_MUL("%8", "%6") SPX_CM_MUL("%9", "%7") SPX_CM_FMA("%8", "%6", NEG) SPX_CM_FMA("%9", "%7", NEG)
+    if constexpr (CONJ)
+        asm(SPX_CM_BODY("neg_hi")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(t0), "=&v"(t1)
+            : "v"(w));
+    else
+        asm(SPX_CM_BODY("neg_lo")
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(t0), "=&v"(t1)
+            : "v"(w));
+#undef SPX_CM_BODY
+#undef SPX_CM_FMA
+#undef SPX_CM_MUL
+}
+// Complex arithmetic on operands that arrive as STRUCTURE-OF-ARRAYS register pairs: a 16-byte LDS
+// read of four real (or four imaginary) parts lands in four consecutive registers, i.e. two aligned
+// pairs a = (p_j, p_j+1).  VOP3P's op_sel picks either half of a pair for BOTH result lanes, so a
+// product of a complex number given as (re in one pair, im in another) with w costs the same two
+// packed instructions as cmul on an (re, im) pair and no moves to build that pair first:
+//   bcast_mul<S>(a, w)         = (a[S] w.x,  a[S] w.y)          CONJ: (a[S] w.x, -a[S] w.y)
+//   bcast_fma_rot<S>(a, w, c)  = c + a[S] (-w.y, w.x)           CONJ: c + a[S] (w.y, w.x)
+// so that (re + i im) w = bcast_fma_rot<S>(IM, w, bcast_mul<S>(RE, w)), and with CONJ the product
+// with conj(w).
+template <int S, bool CONJ = false> SPX_DEVICE f32x2 bcast_mul(f32x2 a, f32x2 w) {
+    f32x2 r;
+    if constexpr (S == 0 && !CONJ) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(w));
+    if constexpr (S == 1 && !CONJ) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(w));
+    if constexpr (S == 0 && CONJ) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(w));
+    if constexpr (S == 1 && CONJ) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+template <int S, bool CONJ = false> SPX_DEVICE f32x2 bcast_fma_rot(f32x2 a, f32x2 w, f32x2 c) {
+    f32x2 r;
+    if constexpr (S == 0 && !CONJ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(c));
+    if constexpr (S == 1 && !CONJ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(c));
+    if constexpr (S == 0 && CONJ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(c));
+    if constexpr (S == 1 && CONJ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(c));
+    return r;
+}
 // d += t * w IN PLACE: two fused multiply-adds, no temporary
 SPX_DEVICE void cmac_ip(f32x2& d, f32x2 t, f32x2 w) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]\n\t"
@@ -202,6 +254,11 @@ SPX_DEVICE void consume(float v) { asm volatile("" ::"v"(v)); }
 // stops the instruction scheduler from moving anything across this point (used to
 // keep independent butterflies from being interleaved into a register-pressure spike)
 SPX_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+// one 4-byte LDS read that the compiler may not merge with its neighbours into a wider one
+SPX_DEVICE float lds_read_f32(const float* p) {
+    return *(const volatile __attribute__((address_space(3))) float*)p;
+}
 
 // same, but also orders the wave's GLOBAL stores before its later loads (vmcnt drain)
 SPX_DEVICE void wave_sync_mem() {

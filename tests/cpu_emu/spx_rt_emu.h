@@ -88,6 +88,20 @@ SPX_DEVICE f32x2 cmulc(f32x2 a, f32x2 w) { return f32x2{a.x * w.x + a.y * w.y, a
 SPX_DEVICE void cmac_ip(f32x2& d, f32x2 t, f32x2 w) { const f32x2 p = cmul(t, w); d = f32x2{d.x + p.x, d.y + p.y}; }
 SPX_DEVICE void cmul_ip(f32x2& a, f32x2 w) { a = cmul(a, w); }
 SPX_DEVICE void cmulc_ip(f32x2& a, f32x2 w) { a = cmulc(a, w); }
+template <bool CONJ>
+SPX_DEVICE void cmul8_ip(f32x2& a0, f32x2& a1, f32x2& a2, f32x2& a3, f32x2& a4, f32x2& a5, f32x2& a6, f32x2& a7,
+                         f32x2 w) {
+    f32x2* a[8] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7};
+    for (int i = 0; i < 8; ++i) *a[i] = CONJ ? cmulc(*a[i], w) : cmul(*a[i], w);
+}
+template <int S, bool CONJ = false> SPX_DEVICE f32x2 bcast_mul(f32x2 a, f32x2 w) {
+    const float x = S ? a.y : a.x;
+    return f32x2{x * w.x, CONJ ? x * -w.y : x * w.y};
+}
+template <int S, bool CONJ = false> SPX_DEVICE f32x2 bcast_fma_rot(f32x2 a, f32x2 w, f32x2 c) {
+    const float x = S ? a.y : a.x;
+    return f32x2{std::fmaf(x, CONJ ? w.y : -w.y, c.x), std::fmaf(x, w.x, c.y)};
+}
 SPX_DEVICE f32x2 add_mi(f32x2 s, f32x2 d) { return f32x2{s.x + d.y, s.y - d.x}; }
 SPX_DEVICE f32x2 add_pi(f32x2 s, f32x2 d) { return f32x2{s.x - d.y, s.y + d.x}; }
 SPX_DEVICE f32x2 neg_add_mi(f32x2 d) { return f32x2{d.y - d.x, -d.x - d.y}; }
@@ -95,6 +109,7 @@ SPX_DEVICE f32x2 neg_add_pi(f32x2 d) { return f32x2{-d.x - d.y, d.x - d.y}; }
 SPX_DEVICE f32x2 fma_pk(f32x2 a, f32x2 b, f32x2 c) { return f32x2{std::fmaf(a.x, b.x, c.x), std::fmaf(a.y, b.y, c.y)}; }
 SPX_DEVICE f32x2 fma_swap(f32x2 a, f32x2 b, f32x2 c) { return f32x2{std::fmaf(a.y, b.x, c.x), std::fmaf(a.x, b.y, c.y)}; }
 template <int P> SPX_DEVICE void set_prio() {}
+SPX_DEVICE float lds_read_f32(const float* p) { return *p; }
 SPX_DEVICE void consume(float v) { (void)v; }
 SPX_DEVICE void sched_fence() {}
 
