@@ -809,6 +809,12 @@ SPX_DEVICE int plane_col(int row, int col) { return col ^ (((row & 1) << 4) | ((
 // moves that used to build the pair first (~190 of a wave's ~1350 non-arithmetic vector
 // instructions per pair).
 // ---------------------------------------------------------------------------
+// Reference mode's eight-transform kernel with transpose_tile_cplx: 0 spilled registers instead of 4 (235-237
+// VGPRs) and 0.4-0.9 % SLOWER on the fold path that uses it (profiles/r03/disp5_cplxt_ab.txt: the half-wave
+// reads cost more than four spilled registers do).  Shipped: 0 = the faster one, with its 4 spills.
+#ifndef SPX_DISP5_CPLXT
+#define SPX_DISP5_CPLXT 0
+#endif
 // MEASURED AND NOT ADOPTED (SPX_FUSED_TW = 0 is the shipped path; -DSPX_FUSED_TW=1 builds the variant;
 // profiles/r03/variants_b1t0_fused.txt, sq_summary_fused.json): 8.5 % fewer vector instructions per pair
 // (16.3k -> 14.9k), the same 3.92 ms per 1e5 pairs -- the time went into waits instead (SQ_WAIT_INST_LDS
@@ -937,7 +943,9 @@ SPX_DEVICE float fold_tile(cf (&v)[8][8]) {
 // cc_planes: staged input planes -> the NCLS real class planes d_c in LDS.
 // Caller must have issued a block_sync after staging; ends with a block_sync.
 // ---------------------------------------------------------------------------
-template <int C, int DBG = 0, bool FOLD = false>
+// CPLXT: transpose_tile_cplx (whole complex elements, no re-pairing moves, ~19 registers fewer) instead of
+// transpose_tile: for callers that sit at the 256-register budget (reference mode: its spills go away).
+template <int C, int DBG = 0, bool FOLD = false, bool CPLXT = false>
 SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, int rot = 0) {
     typedef Lds<C> L;
     typedef StageGeom<C, FOLD> G;
@@ -1054,6 +1062,8 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
         for (int x0 = 1; x0 < 8; ++x0) wxa[x0] = tw[x0 * (cx + C * l0)];
         wxa[0] = cf{1.0f, 0.0f};
         transpose_tile_tw<L::XS, false, true>(v, xch, lane, wxa);
+    } else if constexpr (CPLXT) {
+        transpose_tile_cplx<L::XS>(v, xch, lane);
     } else {
         transpose_tile_sel<L::XS>(v, xch, lane);
     }
@@ -1103,6 +1113,8 @@ SPX_DEVICE bool cc_planes(unsigned char* lds, float bal, PhaseClock<DBG>& clk, i
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) wxb[kb] = tw[l0 * (cx + C * kb)];
         transpose_tile_tw<L::XS, true, false>(v, xch, lane, wxb);
+    } else if constexpr (CPLXT) {
+        transpose_tile_cplx<L::XS>(v, xch, lane);
     } else {
         transpose_tile_sel<L::XS>(v, xch, lane);
     }
@@ -1876,7 +1888,7 @@ SPX_DEVICE void disp5_body(const TIn* __restrict__ ref, const TIn* __restrict__ 
         const float bal = balance_factor(scr, ssq);
         const float oscale = 0.5f / ((float)(L::P * L::P) * bal);
         PhaseClock<0> noclk;
-        cc_planes<C, 0, FOLD>(lds, bal, noclk);
+        cc_planes<C, 0, FOLD, SPX_DISP5_CPLXT>(lds, bal, noclk);
         interlace_window<C, FOLD>(lds, ny, nx, oscale, icc, ox, oy, bv, bi);
         rt::block_sync_lds();                    // planes are overwritten by the next stage
     }
