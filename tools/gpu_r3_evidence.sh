@@ -22,6 +22,12 @@ done
 cd $GRAFT_REPO_ROOT
 step "SQ counters"; SPX_PAIR64_WAVES=4 bash tools/gpu_sq.sh w4 > $O/sq_w4.log 2>&1 || { tail -5 $O/sq_w4.log; exit 1; }
 cp gpurun_out/sq_summary_w4.json $O/; cp gpurun_out/sq_flops_64_u10_w4.json $O/sq_flops_64_u10.json 2>/dev/null
+# the traffic / FLOP files of THIS build now exist: put them where bench.py looks (profiles/r03, fingerprint-checked)
+# and take the default bench line again, so that the committed line carries traffic and compute_fraction
+step "bench again, with this build's counter files"
+mv $O/bench.json $O/bench_first.json
+cp $O/pmc_traffic*.json $O/sq_flops_64_u10.json profiles/r03/ 2>/dev/null
+$B > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
 step "phase stamps"; WAVES=4 timeout -k 10 300 python tools/phase_cycles.py > $O/phase_cycles64.txt 2>&1 || tail -3 $O/phase_cycles64.txt
 timeout -k 10 300 python tools/phase_cycles128.py > $O/phase_cycles128.txt 2>&1 || tail -3 $O/phase_cycles128.txt
 step "rates"; for cfg in "128 20" "96 10" "80 10" "32 10"; do set -- $cfg
