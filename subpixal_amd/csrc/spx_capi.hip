@@ -123,22 +123,36 @@ struct TableLock {
     }
 };
 
-// interpolation tables of one tile family for `upsample` (nullptr for upsample 1); caller holds g_mu
-int ktab_for(DeviceTables* t, Tile tile, int upsample, const float** out) {
+// interpolation tables of one tile family for `upsample` (nullptr for upsample 1); caller holds g_mu.
+// `f64_64`: the 64 tile's tables as float64 in the float64 MFMA's result order (make_ktab_f64), for a four-wave
+// kernel built with the float64 refine (spx::kRefine64F64); the eight-wave A/B kernel always reads float32 ones.
+int ktab_for(DeviceTables* t, Tile tile, int upsample, const float** out, bool f64_64 = false) {
     *out = nullptr;
     const int wb = spx::host::window_blocks(upsample);
     if (wb <= 0) return 0;
-    auto it = t->ktab[tile].find(upsample);
+    f64_64 = f64_64 && tile == TILE64;
+    const int key = upsample + (f64_64 ? (1 << 20) : 0);
+    auto it = t->ktab[tile].find(key);
     if (it == t->ktab[tile].end()) {
         float* p = nullptr;
         // period 192: float64 tables (its refine stage accumulates in float64)
         const int rc = tile == TILE32 ? upload(spx::host::make_ktab32(upsample, 16 * wb), &p)
-                     : tile == TILE64 ? upload(spx::host::make_ktab(128, upsample, 16 * wb), &p)
+                     : tile == TILE64 ? (f64_64 ? upload(spx::host::make_ktab_f64(128, upsample, 16 * wb), &p)
+                                                : upload(spx::host::make_ktab(128, upsample, 16 * wb), &p))
                                       : upload(spx::host::make_ktab_big_f64(192, upsample, 16 * wb), &p);
         if (rc) return rc;
-        it = t->ktab[tile].emplace(upsample, p).first;
+        it = t->ktab[tile].emplace(key, p).first;
     }
     *out = it->second;
+    return 0;
+}
+// both forms of a pair-mode launch's tables: `ktab` for the kernel family's own refine, `ktab_f32` for the
+// eight-wave 64-tile kernel (the same pointer unless the four-wave kernel refines in float64)
+int pair_tables_for(DeviceTables* t, Tile tile, int upsample, const float** ktab, const float** ktab_f32) {
+    int rc = ktab_for(t, tile, upsample, ktab, spx::kRefine64F64);
+    if (rc) return rc;
+    if (tile == TILE64 && spx::kRefine64F64) return ktab_for(t, tile, upsample, ktab_f32, false);
+    *ktab_f32 = *ktab;
     return 0;
 }
 
@@ -222,6 +236,7 @@ struct PairArgs {
     int64_t nbatch;
     int ny, nx, U, cc_type;
     const float* ktab;
+    const float* ktab_f32;       // for the eight-wave 64-tile kernel (pair_tables_for)
     double* out;
     int32_t* status;
     float* ws;
@@ -248,7 +263,7 @@ int run_pair64_w8(DeviceTables* t, const TIn* ref, const TIn* img, const PairArg
     int rc = allow_lds(t, kern, lds);
     if (rc || !launch) return rc;
     hipLaunchKernelGGL(kern, dim3(grid_for(t, a.nbatch)), dim3(spx::w8::kT8), lds, a.s, ref, img,
-                       a.nbatch, a.ny, a.nx, a.U, a.cc_type, t->tw[TILE64], a.ktab, a.out, a.status);
+                       a.nbatch, a.ny, a.nx, a.U, a.cc_type, t->tw[TILE64], a.ktab_f32, a.out, a.status);
     SPX_HIP(hipGetLastError());
     return 0;
 }
@@ -470,7 +485,7 @@ int xcorr_refine(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
         lk.enter_launch(t);
         return run_pair_general_wb<TIn>(t, wb, ref, img, a, C, tw, true);
     }
-    rc = ktab_for(t, tile, upsample, &a.ktab);
+    rc = pair_tables_for(t, tile, upsample, &a.ktab, &a.ktab_f32);
     if (rc) return rc;
     lk.enter_launch(t);
     return run_pair<TIn>(t, wb, tile, ny > 64 || nx > 64, ref, img, a, true);
@@ -581,7 +596,8 @@ int spx_prepare(int upsample) {
         std::lock_guard<std::mutex> gl(g_mu);
         for (int k = 0; k < NUM_TILES; ++k) {
             const float* kt = nullptr;
-            if ((rc = ktab_for(t, (Tile)k, upsample, &kt))) return rc;
+            const float* kt32 = nullptr;
+            if ((rc = pair_tables_for(t, (Tile)k, upsample, &kt, &kt32))) return rc;
         }
     }
     for (int k = 0; k < NUM_TILES; ++k) {
@@ -690,7 +706,7 @@ int spx_diag_pair_phase(const float* ref, const float* img, int64_t nbatch, int 
     a.status = out_status; a.ws = nullptr; a.s = reinterpret_cast<hipStream_t>(stream);
     {
         std::lock_guard<std::mutex> gl(g_mu);
-        rc = ktab_for(t, TILE64, 10, &a.ktab);
+        rc = pair_tables_for(t, TILE64, 10, &a.ktab, &a.ktab_f32);
     }
     if (rc) return rc;
     const bool fold = ny > 64 || nx > 64;

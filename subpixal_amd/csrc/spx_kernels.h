@@ -1287,26 +1287,63 @@ SPX_DEVICE PeakResult peak_from_argmax(unsigned char* lds_scr, int imax, int jma
 // the lane-constant K operands of one wave (loaded early, under the coarse arg-max)
 // Up to W = 32 they are held in registers; larger windows (upsample >= 28) fetch them from the
 // L2-resident table where they are used, or the 32 WB registers would spill.
-template <int WB> struct FineTables {
-    static constexpr bool kPreload = WB <= 2;
-    f32x4 ky[kPreload ? WB : 1][4], kx[kPreload ? WB : 1][4];
-    const f32x4* kty;
-    const f32x4* ktx;
-    SPX_DEVICE f32x4 y(int ab, int s4) const { return kPreload ? ky[ab][s4] : kty[ab * 64 * 4 + s4]; }
-    SPX_DEVICE f32x4 x(int bb, int t) const { return kPreload ? kx[bb][t] : ktx[bb * 64 * 4 + t]; }
+// The refine's arithmetic: float32 (v_mfma_f32_16x16x4_f32) or float64 (v_mfma_f64_16x16x4_f64; float64 tables,
+// spx_tables.h make_ktab_f64).  Both take A[i = lane & 15][k = lane >> 4] and B[k = lane >> 4][j = lane & 15];
+// they differ in where result row i lives: register r of lane group lk holds row 4 lk + r (float32) or
+// lk + 4 r (float64) -- `drow`.  Stage 2 consumes stage 1's result registers directly as its B operand, so
+// its table is laid out in the same order (make_ktab / make_ktab_f64).
+// Why float64: like for like against the float64 definition the float64-refine family (period 192) stays at
+// 1-5e-5 px up to upsample 40, the float32-refine tiles are at 5e-5 ... 2.2e-4 from upsample 10 on
+// (profiles/r03/refine_precision.txt); the window values are rounded to float32 either way, it is the two
+// 64-term float32 accumulation chains that cost the digits.
+struct RefineF32 {
+    typedef float S;
+    typedef f32x4 V4;
+    static constexpr int kPreloadMax = 2;        // window blocks whose tables are held in registers
+    static SPX_DEVICE V4 zero() { return V4{0.f, 0.f, 0.f, 0.f}; }
+    static SPX_DEVICE V4 mma(S a, S b, V4 c) { return rt::mfma_16x16x4(a, b, c); }
+    static SPX_DEVICE int drow(int lk, int r) { return 4 * lk + r; }
 };
-template <int C, int WB>
-SPX_DEVICE void load_fine_tables(FineTables<WB>& ft, const float* __restrict__ ktab, int rot = 0) {
+struct RefineF64 {
+    typedef double S;
+    typedef rt::f64x4 V4;
+    static constexpr int kPreloadMax = 1;        // 16 doubles per table slice: 64 registers for one block
+    static SPX_DEVICE V4 zero() { return V4{0.0, 0.0, 0.0, 0.0}; }
+    static SPX_DEVICE V4 mma(S a, S b, V4 c) { return rt::mfma_f64_16x16x4(a, b, c); }
+    static SPX_DEVICE int drow(int lk, int r) { return lk + 4 * r; }
+};
+#ifndef SPX_REFINE64_F64
+#define SPX_REFINE64_F64 0
+#endif
+#if SPX_REFINE64_F64
+typedef RefineF64 Refine64;                      // the 64 tile's refine (pair_kernel, incl. the fold path)
+#else
+typedef RefineF32 Refine64;
+#endif
+constexpr bool kRefine64F64 = SPX_REFINE64_F64 != 0;     // which table the host hands that kernel (spx_tables.h)
+
+template <int WB, typename R = RefineF32> struct FineTables {
+    typedef typename R::V4 V4;
+    static constexpr bool kPreload = WB <= R::kPreloadMax;
+    V4 ky[kPreload ? WB : 1][4], kx[kPreload ? WB : 1][4];
+    const V4* kty;
+    const V4* ktx;
+    SPX_DEVICE V4 y(int ab, int s4) const { return kPreload ? ky[ab][s4] : kty[ab * 64 * 4 + s4]; }
+    SPX_DEVICE V4 x(int bb, int t) const { return kPreload ? kx[bb][t] : ktx[bb * 64 * 4 + t]; }
+};
+template <int C, int WB, typename R>
+SPX_DEVICE void load_fine_tables(FineTables<WB, R>& ft, const float* __restrict__ ktab, int rot = 0) {
+    typedef typename R::V4 V4;
     const int tid = fresh_tid();
     const int wave = ((tid >> 6) + rot) & (C * C - 1), lane = tid & 63;     // class, see cc_planes
     const int cy = wave / C, cx = wave % C;
     ktab = rt::launder(ktab);
-    // table slices of this lane: [2 (y|x)][2 (class)][WB][64 lanes][16]
-    const f32x4* kty = reinterpret_cast<const f32x4*>(ktab) + ((size_t)(0 * 2 + cy) * WB * 64 + lane) * 4;
-    const f32x4* ktx = reinterpret_cast<const f32x4*>(ktab) + ((size_t)(1 * 2 + cx) * WB * 64 + lane) * 4;
+    // table slices of this lane: [2 (y|x)][2 (class)][WB][64 lanes][16] elements of R::S
+    const V4* kty = reinterpret_cast<const V4*>(ktab) + ((size_t)(0 * 2 + cy) * WB * 64 + lane) * 4;
+    const V4* ktx = reinterpret_cast<const V4*>(ktab) + ((size_t)(1 * 2 + cx) * WB * 64 + lane) * 4;
     ft.kty = kty;
     ft.ktx = ktx;
-    if constexpr (FineTables<WB>::kPreload) {
+    if constexpr (FineTables<WB, R>::kPreload) {
 #pragma unroll
         for (int b = 0; b < WB; ++b)
 #pragma unroll
@@ -1317,10 +1354,12 @@ SPX_DEVICE void load_fine_tables(FineTables<WB>& ft, const float* __restrict__ k
     }
 }
 
-template <int C, int WB>
-SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB>& ft,
+template <int C, int WB, typename R>
+SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB, R>& ft,
                             int ny, int nx, int qyc, int qxc, int rot = 0) {
     typedef Lds<C> L;
+    typedef typename R::S S;
+    typedef typename R::V4 V4;
     static_assert(C == 2, "");
     constexpr int W = 16 * WB;
     const int tid = fresh_tid();
@@ -1333,11 +1372,11 @@ SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB>& ft,
 
     // d_c[m] = (-1)^(c floor(m/64)) plane[m mod 64]: the sign of a wrapped row goes
     // into the K operand of that row, the sign of a wrapped column likewise.
-    f32x4 acc[WB][4];
+    V4 acc[WB][4];
 #pragma unroll
     for (int ab = 0; ab < WB; ++ab)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[ab][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 4; ++t) acc[ab][t] = R::zero();
     int col[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) col[t] = (lxc + 16 * t + lj - 32) & 63;
@@ -1354,46 +1393,46 @@ SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB>& ft,
     }
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-        f32x4 kb[WB];
+        V4 kb[WB];
 #pragma unroll
         for (int ab = 0; ab < WB; ++ab) kb[ab] = ft.y(ab, s4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int step = 4 * s4 + e;
             const int m = lyc + 4 * step + lk - 32;
-            const float sgn = (cy && ((m >> 6) & 1)) ? -1.0f : 1.0f;
+            const S sgn = (cy && ((m >> 6) & 1)) ? (S)-1 : (S)1;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
 #pragma unroll
                 for (int ab = 0; ab < WB; ++ab)
-                    acc[ab][t] = rt::mfma_16x16x4(afrag[step][t], sgn * kb[ab][e], acc[ab][t]);
+                    acc[ab][t] = R::mma((S)afrag[step][t], sgn * kb[ab][e], acc[ab][t]);
             }
         }
     }
     // stage 2: F^T[b][a] = sum_mx'' sgn_x K_cx[b][mx''] G^T[mx''][a]; accumulator register
-    // r of tile t is B-operand row k' = lane>>4 for mx'' = 16 t + 4 k' + r - 32.
-    f32x4 f[WB][WB];
+    // r of tile t is B-operand row k' = lane>>4 for mx'' = 16 t + R::drow(k', r) - 32.
+    V4 f[WB][WB];
 #pragma unroll
     for (int bb = 0; bb < WB; ++bb)
 #pragma unroll
-        for (int ab = 0; ab < WB; ++ab) f[bb][ab] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ab = 0; ab < WB; ++ab) f[bb][ab] = R::zero();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        f32x4 ka[WB];
+        V4 ka[WB];
 #pragma unroll
         for (int bb = 0; bb < WB; ++bb) ka[bb] = ft.x(bb, t);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = lxc + 16 * t + 4 * lk + r - 32;
-            const float sgn = (cx && ((m >> 6) & 1)) ? -1.0f : 1.0f;
+            const int m = lxc + 16 * t + R::drow(lk, r) - 32;
+            const S sgn = (cx && ((m >> 6) & 1)) ? (S)-1 : (S)1;
 #pragma unroll
             for (int bb = 0; bb < WB; ++bb)
 #pragma unroll
                 for (int ab = 0; ab < WB; ++ab)
-                    f[bb][ab] = rt::mfma_16x16x4(sgn * ka[bb][r], acc[ab][t][r], f[bb][ab]);
+                    f[bb][ab] = R::mma(sgn * ka[bb][r], acc[ab][t][r], f[bb][ab]);
         }
     }
-    const float scale = 0.5f / (float)(L::P * L::P);
+    const S scale = (S)0.5 / (S)(L::P * L::P);
     if constexpr (L::fb_count(W) == C * C) {
         // one window per class; the reader adds the four in fixed order (fine_value)
         float* mine = fbuf + wave * W * W;
@@ -1403,7 +1442,7 @@ SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB>& ft,
             for (int ab = 0; ab < WB; ++ab)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    mine[(bb * 16 + 4 * lk + r) * W + ab * 16 + lj] = f[bb][ab][r] * scale;
+                    mine[(bb * 16 + R::drow(lk, r)) * W + ab * 16 + lj] = (float)(f[bb][ab][r] * scale);
         rt::block_sync_lds();
     } else {
         // large windows: accumulate the 4 classes in fixed order into one buffer
@@ -1415,8 +1454,8 @@ SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB>& ft,
                     for (int ab = 0; ab < WB; ++ab)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int b = bb * 16 + 4 * lk + r, a = ab * 16 + lj;
-                            const float val = f[bb][ab][r] * scale;
+                            const int b = bb * 16 + R::drow(lk, r), a = ab * 16 + lj;
+                            const float val = (float)(f[bb][ab][r] * scale);
                             if (c == 0) fbuf[b * W + a] = val; else fbuf[b * W + a] += val;
                         }
             }
@@ -1602,8 +1641,8 @@ SPX_DEVICE void pair_body(const TIn* __restrict__ ref, const TIn* __restrict__ i
     // the refine stage's constant operands: issue the loads now, use them after the arg-max -- and BEFORE the
     // warm-up below: vmcnt counts in issue order, so a wait for the tables must not include the warm-up's
     // trip to HBM (+1.3 %, profiles/r03/variants_*.txt)
-    FineTables<(WB > 0 ? WB : 1)> ft;
-    if constexpr (WB > 0) load_fine_tables<C, WB>(ft, ktab, rot);
+    FineTables<(WB > 0 ? WB : 1), Refine64> ft;
+    if constexpr (WB > 0) load_fine_tables<C, WB, Refine64>(ft, ktab, rot);
     // pull the next pair into L2 while this one is in its tail (issuing it before the transforms instead
     // was measured 2 % slower)
     if constexpr (sizeof(TIn) == 4) if (next_ref) warm = warm_next_pair(next_ref, next_img);
@@ -1636,7 +1675,7 @@ SPX_DEVICE void pair_body(const TIn* __restrict__ ref, const TIn* __restrict__ i
         int imax = 0, jmax = 0;
         bool inside = false;
         for (int iter = 0; iter < 4; ++iter) {
-            fine_window<C, (WB > 0 ? WB : 1)>(lds, ft, ny, nx, qyc, qxc, rot);
+            fine_window<C, (WB > 0 ? WB : 1), Refine64>(lds, ft, ny, nx, qyc, qxc, rot);
             clk.tick(12);
             if constexpr (DBG == 12) { if (tid == 0) out[0] = (double)fine_value<C, W>(lds, 0, 0); return; }
             // arg-max over the part of the window inside the virtual image: every wave scans

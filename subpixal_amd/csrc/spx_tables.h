@@ -68,6 +68,26 @@ inline std::vector<float> make_ktab(int P, int U, int W) {
     return k;
 }
 
+// The same tables in float64 for the 64 tile's float64 refine (spx_kernels.h RefineF64).  Stage 1 as above; stage 2
+// follows v_mfma_f64_16x16x4_f64's result layout (register r of lane group lk holds row lk + 4 r):
+//   [1][c][blk][lane][4 t + r] = K_c( -(16 blk + lj - W/2)/U - (16 t + lk + 4 r - 32) )
+inline std::vector<double> make_ktab_f64(int P, int U, int W) {
+    const int blocks = W / 16;
+    std::vector<double> k((size_t)2 * 2 * blocks * 64 * 16);
+    for (int which = 0; which < 2; ++which)
+        for (int c = 0; c < 2; ++c)
+            for (int blk = 0; blk < blocks; ++blk)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 16; ++i) {
+                        const int lk = lane >> 4, lj = lane & 15;
+                        const int m = which == 0 ? (4 * i + lk - 32)
+                                                 : (16 * (i >> 2) + lk + 4 * (i & 3) - 32);
+                        const double t = -(double)(16 * blk + lj - W / 2) / (double)U - (double)m;
+                        k[((((size_t)which * 2 + c) * blocks + blk) * 64 + lane) * 16 + i] = class_kernel(c, P, t);
+                    }
+    return k;
+}
+
 // 32 tile (period 64, 32-lag class planes), spx_kernels32.h fine_window32:
 //   [0][c][blk][lane][s]       = K_c( -(16 blk + lj - W/2)/U - (4 s + lk - 16) ),        s in [0,8)
 //   [1][c][blk][lane][4 t + r] = K_c( -(16 blk + lj - W/2)/U - (16 t + 4 lk + r - 16) ), t in [0,2)

@@ -46,9 +46,10 @@ static int emu_pair64(const TIn* ref, const TIn* img, int64_t nbatch, int ny, in
     const int wb = host::window_blocks(U);
     std::vector<float> tw = host::make_twiddles(128);
     std::vector<float> kt;
-    if (wb > 0) kt = host::make_ktab(128, U, 16 * wb);
+    std::vector<double> ktd;                      // the float64 refine's tables (spx::kRefine64F64)
+    if (wb > 0) { if (kRefine64F64) ktd = host::make_ktab_f64(128, U, 16 * wb); else kt = host::make_ktab(128, U, 16 * wb); }
     const cf* twp = reinterpret_cast<const cf*>(tw.data());
-    const float* ktp = kt.empty() ? nullptr : kt.data();
+    const float* ktp = wb <= 0 ? nullptr : kRefine64F64 ? reinterpret_cast<const float*>(ktd.data()) : kt.data();
     auto run = [&](auto fn) {
         rt::launch(g_grid > 0 && g_grid < nbatch ? g_grid : nbatch, kThreads, fn, Lds<2>::total(16 * wb));
     };

@@ -23,9 +23,11 @@ from oracle import subpixal_oracle as orc              # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--count', type=int, default=128)
 ap.add_argument('--budget', type=float, default=400.0, help='seconds')
+ap.add_argument('--refine64', default='float32', choices=['float32', 'float64'],
+                help='what the loaded library\'s 64-tile kernel refines in (labels only: a -DSPX_REFINE64_F64=1 build is float64)')
 a = ap.parse_args()
 
-FAMILIES = [(64, '64 tile, float32 refine'), (80, 'fold path, float32 refine'),
+FAMILIES = [(64, '64 tile, %s refine' % a.refine64), (80, 'fold path, %s refine' % a.refine64),
             (96, 'period 192, float64 refine'), (128, 'period 192, float64 refine')]
 UPS = [1, 2, 10, 20, 28, 40]
 t0 = time.time()
