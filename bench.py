@@ -70,14 +70,16 @@ def _cpu_worker(args):
     return out
 
 
-def kernel_name(tile, upsample):
+def kernel_name(tile, upsample, refine='default'):
     """Template instance the C-ABI dispatches to (spx_capi.hip): refinement-window blocks
     WB = 0 for upsample 1, else ceil((upsample + 5) / 16)."""
     wb = 0 if upsample == 1 else (upsample + 5 + 15) // 16
     if tile <= 32:
         return 'spx::pair32_kernel<%d, float>' % wb
     if tile <= 85:
-        return 'spx::pair_kernel<2, %d, 0, %s, float>' % (wb, 'true' if tile > 64 else 'false')
+        # the default refine arithmetic (float32) of the 64 tile; spx::RefineF64 is the SPX_REFINE_F64 form
+        arith = 'RefineF64' if refine == 'float64' and wb > 0 else 'RefineF32'
+        return 'spx::pair_kernel<2, %d, 0, %s, float, spx::%s>' % (wb, 'true' if tile > 64 else 'false', arith)
     return 'spx::pair128_kernel<3, %d, 0, float>' % wb
 
 
@@ -296,6 +298,9 @@ def main():
                     help='skip the reference-mode (cc.find_displacement) block of the N=1 line')
     ap.add_argument('--tile', type=int, default=TILE, help='cutout side (64 = config 2, 128 = config 3)')
     ap.add_argument('--upsample', type=int, default=UPSAMPLE)
+    ap.add_argument('--refine', default='default', choices=['default', 'float64'],
+                    help="arithmetic of the refine stage (SPX_REFINE_*): 'float64' = the slower, more precise form of the "
+                         "64 tile / fold path; the graded line is the default")
     ap.add_argument('--backend', default='nccl', help="'gloo' + --one-device rehearses the N>1 path on one GPU")
     ap.add_argument('--one-device', action='store_true', help='every rank uses cuda:0 (rehearsal only)')
     args = ap.parse_args()
@@ -353,7 +358,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        d = subpixal_amd.xcorr_refine_batch(ref, img, upsample=ups)
+        d = subpixal_amd.xcorr_refine_batch(ref, img, upsample=ups, refine=args.refine)
         g = gather(d)
         return d, g
 
@@ -379,7 +384,7 @@ def main():
     pending = None
     for k in range(args.steps):
         ev[k][0].record()                 # torch's current stream == the launch stream
-        d = subpixal_amd.xcorr_refine_batch(ref, img, upsample=ups)
+        d = subpixal_amd.xcorr_refine_batch(ref, img, upsample=ups, refine=args.refine)
         ev[k][1].record()
         if pending is not None:
             pending.result()
@@ -405,8 +410,10 @@ def main():
         name = 'pmc_traffic.json' if (tile == TILE and ups == UPSAMPLE) else 'pmc_traffic_%d_u%d.json' % (tile, ups)
         traffic, traffic_src = None, None
         pmc, src = _profile_json(name)
-        if pmc is not None and pmc.get('pairs_per_launch') == n_local and pmc.get('tile', TILE) == tile and \
-                pmc.get('upsample', UPSAMPLE) == ups:
+        # (the counter files were taken on the default refine form: a --refine float64 line quotes none of them)
+        counters_apply = args.refine == 'default' or tile <= 32 or tile > 85
+        if counters_apply and pmc is not None and pmc.get('pairs_per_launch') == n_local and \
+                pmc.get('tile', TILE) == tile and pmc.get('upsample', UPSAMPLE) == ups:
             traffic, traffic_src = pmc['hbm_bytes_per_launch'], src
         value = n_total * args.steps / elapsed
         achieved = n_local * bytes_per_pair / (kern_ms * 1e-3) / 1e9
@@ -430,7 +437,7 @@ def main():
                                ' (1e7 pairs over 8 GPUs)' if config4 else
                                ' shape, on the GPU' if tile <= 32 else ('' if tile in (64, 128) else ' family'),
                                n_local, tile, tile, ups),
-                'pairs_per_gpu': n_local, 'tile': tile, 'upsample': ups, 'cc_type': 'CC',
+                'pairs_per_gpu': n_local, 'tile': tile, 'upsample': ups, 'cc_type': 'CC', 'refine': args.refine,
                 'parallelism': 'batch sharded over %d GPU(s); gather of (dx,dy) to rank 0' % world,
             },
             'roofline': {
@@ -443,13 +450,13 @@ def main():
                 'traffic_unit': 'HBM bytes per launch from the PMC passes of the same command on this kernel '
                                 'build (%s); null = not measured for this build/config' % traffic_src,
                 'algorithmic_bytes_per_launch': n_local * bytes_per_pair,
-                'kernel': kernel_name(tile, args.upsample),
+                'kernel': kernel_name(tile, args.upsample, args.refine),
                 'kernel_ms': kern_ms,
                 'bytes_per_pair': bytes_per_pair,
                 'pairs_per_launch': n_local,
             },
         }
-        fl = flops_per_pair(tile, ups, n_local)
+        fl = flops_per_pair(tile, ups, n_local) if counters_apply else None
         if fl is not None:
             tf = fl[0] * 1e6 * n_local / (kern_ms * 1e-3) / 1e12
             out['roofline'].update({

@@ -70,7 +70,7 @@
 extern "C" {
 #endif
 
-#define SPX_ABI_VERSION 3
+#define SPX_ABI_VERSION 4
 
 /* cc_type (cc.py:107-111; anything else than NCC/ZNCC means plain CC) */
 #define SPX_CC 0
@@ -153,6 +153,30 @@ int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int
 int spx_xcorr_refine_f64(const double* ref, const double* img, int64_t nbatch, int ny, int nx,
                          int upsample, int cc_type, double* out_dxdy, int32_t* out_status,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * The same with the arithmetic of the refine stage (the U-times upsampling around the coarse maximum,
+ * upsample > 1) chosen by the caller.  The transforms are float32 either way.
+ *   SPX_REFINE_DEFAULT  what spx_xcorr_refine_f32 / _f64 do: float32 matrix products up to 85 px per side,
+ *                       float64 above (the period-192 and general paths have only that form).
+ *   SPX_REFINE_F64      float64 accumulation on cutouts of 33..85 px as well (the 64 tile and its fold path).
+ *                       Measured on one MI355X against the float64 definition, noise-free 4..6-px-sigma spots
+ *                       (profiles/r03/refine_precision*.txt): 64 px at upsample 10 / 20 / 40: 1.2e-5 / 2.3e-5 /
+ *                       4.5e-5 px instead of 5.5e-5 / 1.3e-4 / 1.3e-4; and 14 % / 21 % fewer pairs per second at
+ *                       upsample 10 / 20 (profiles/r03/refine64_throughput_ab.txt).  Both are inside the 1e-3 px
+ *                       this library promises; the flag buys the margin, not the promise.
+ *                       Cutouts up to 32 px per side have no float64 form and are refined in float32 with either
+ *                       value; upsample >= 43 on 33..85 px runs with ~50 spilled registers in this form (slower).
+ * Any other value: SPX_E_ARG.
+ */
+#define SPX_REFINE_DEFAULT 0
+#define SPX_REFINE_F64 1
+int spx_xcorr_refine_ex_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
+                            int upsample, int cc_type, int refine, double* out_dxdy, int32_t* out_status,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int spx_xcorr_refine_ex_f64(const double* ref, const double* img, int64_t nbatch, int ny, int nx,
+                            int upsample, int cc_type, int refine, double* out_dxdy, int32_t* out_status,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Reference mode (cc.find_displacement).  ref: float32 [nbatch][ny][nx];

@@ -10,7 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SPX_HIP_LIB: another build of the same library (A/B measurements only: tools/gpu_r3_variants.sh)
 LIB_PATH = os.environ.get('SPX_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libsubpixal_hip.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
+REFINE_DEFAULT, REFINE_F64 = 0, 1         # SPX_REFINE_* (include/subpixal_hip.h)
 MAX_SIDE = 682
 MAX_UPSAMPLE = 59
 MAX_UPSAMPLE_GENERAL = 39      # cutouts above 128 px
@@ -35,6 +36,11 @@ _SIGNATURES = {
                                         _c.c_int, _vp, _vp, _vp, _c.c_size_t, _vp]),
     'spx_xcorr_refine_f64': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                         _c.c_int, _vp, _vp, _vp, _c.c_size_t, _vp]),
+    # ... with the refine stage's arithmetic chosen per call (REFINE_DEFAULT / REFINE_F64)
+    'spx_xcorr_refine_ex_f32': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
+                                           _c.c_int, _c.c_int, _vp, _vp, _vp, _c.c_size_t, _vp]),
+    'spx_xcorr_refine_ex_f64': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
+                                           _c.c_int, _c.c_int, _vp, _vp, _vp, _c.c_size_t, _vp]),
     'spx_find_displacement5_f32': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int,
                                               _c.c_int, _vp, _vp, _vp, _vp, _c.c_size_t, _vp]),
     'spx_find_displacement5_f64': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int,

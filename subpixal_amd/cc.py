@@ -42,7 +42,7 @@ def _input_dtype(*arrays):
     return torch.float64 if all(is64(a) for a in arrays) else torch.float32
 
 
-def xcorr_refine_batch(ref, img, upsample=1, cc_type='CC', return_status=False):
+def xcorr_refine_batch(ref, img, upsample=1, cc_type='CC', return_status=False, refine='default'):
     """Shifts of ``img[k]`` relative to ``ref[k]`` for a batch of cutout pairs.
 
     ref, img : ``[N, ny, nx]`` float32 or float64, torch CUDA tensors (used in place) or
@@ -54,9 +54,18 @@ def xcorr_refine_batch(ref, img, upsample=1, cc_type='CC', return_status=False):
         ``upsample=2`` is the reference's half-pixel interlace (cc.py:121-126),
         ``upsample=1`` is ``fftconvolve(..,'same')`` + ``find_peak`` on one image.
 
+    refine : ``'default'`` or ``'float64'`` -- the arithmetic of that refinement (``SPX_REFINE_*``).  The
+        default is float32 matrix products on cutouts up to 85 px per side and float64 above; ``'float64'``
+        accumulates in float64 on 33..85 px as well: 4-7x closer to the float64 definition (64 px,
+        upsample 10: 1.2e-5 instead of 5.5e-5 px) for 14 % fewer pairs per second there -- both well inside
+        the 1e-3 px tolerance (``profiles/r03/refine_precision*.txt``, ``refine64_throughput_ab.txt``).
+        Cutouts up to 32 px are refined in float32 either way.
+
     Returns ``dxdy [N, 2]`` float64 (torch CUDA tensor if the inputs were
     tensors, else numpy) and, with ``return_status``, the int32 ``status [N]``.
     """
+    if refine not in ('default', 'float64'):
+        raise ValueError("refine must be 'default' or 'float64'.")
     like_torch = isinstance(ref, torch.Tensor)
     dt = _input_dtype(ref, img)
     r = device.to_device(ref, dt)
@@ -69,9 +78,10 @@ def xcorr_refine_batch(ref, img, upsample=1, cc_type='CC', return_status=False):
     lib = _ffi.load()
     with torch.cuda.device(r.device):
         ws, ws_bytes = _workspace(lib.spx_workspace_bytes_xcorr(n, ny, nx), r.device)
-        fn = lib.spx_xcorr_refine_f64 if dt == torch.float64 else lib.spx_xcorr_refine_f32
+        fn = lib.spx_xcorr_refine_ex_f64 if dt == torch.float64 else lib.spx_xcorr_refine_ex_f32
         _ffi.check(fn(
             device.ptr(r), device.ptr(m), n, ny, nx, int(upsample), _cc_code(cc_type),
+            _ffi.REFINE_F64 if refine == 'float64' else _ffi.REFINE_DEFAULT,
             device.ptr(out), device.ptr(status), device.ptr(ws), ws_bytes, device.stream_ptr()))
     if return_status:
         return _finish(out, like_torch), _finish(status, like_torch)

@@ -124,8 +124,8 @@ struct TableLock {
 };
 
 // interpolation tables of one tile family for `upsample` (nullptr for upsample 1); caller holds g_mu.
-// `f64_64`: the 64 tile's tables as float64 in the float64 MFMA's result order (make_ktab_f64), for a four-wave
-// kernel built with the float64 refine (spx::kRefine64F64); the eight-wave A/B kernel always reads float32 ones.
+// `f64_64`: the 64 tile's tables as float64 in the float64 MFMA's result order (make_ktab_f64), for the four-wave
+// kernel's float64-refine form (PairArgs::refine_f64); the eight-wave A/B kernel always reads float32 ones.
 int ktab_for(DeviceTables* t, Tile tile, int upsample, const float** out, bool f64_64 = false) {
     *out = nullptr;
     const int wb = spx::host::window_blocks(upsample);
@@ -146,13 +146,23 @@ int ktab_for(DeviceTables* t, Tile tile, int upsample, const float** out, bool f
     *out = it->second;
     return 0;
 }
-// both forms of a pair-mode launch's tables: `ktab` for the kernel family's own refine, `ktab_f32` for the
-// eight-wave 64-tile kernel (the same pointer unless the four-wave kernel refines in float64)
-int pair_tables_for(DeviceTables* t, Tile tile, int upsample, const float** ktab, const float** ktab_f32) {
-    int rc = ktab_for(t, tile, upsample, ktab, spx::kRefine64F64);
+// both forms of a pair-mode launch's tables: `ktab` for the kernel family's refine as this call wants it
+// (`refine_f64`: the 64 tile's float64 form), `ktab_f32` for the eight-wave 64-tile kernel (the same pointer
+// unless `ktab` is the float64 table)
+int pair_tables_for(DeviceTables* t, Tile tile, int upsample, bool refine_f64, const float** ktab,
+                    const float** ktab_f32) {
+    int rc = ktab_for(t, tile, upsample, ktab, refine_f64);
     if (rc) return rc;
-    if (tile == TILE64 && spx::kRefine64F64) return ktab_for(t, tile, upsample, ktab_f32, false);
+    if (tile == TILE64 && refine_f64) return ktab_for(t, tile, upsample, ktab_f32, false);
     *ktab_f32 = *ktab;
+    return 0;
+}
+// what a call's `refine` argument means for the 64 tile (the other families have one form each: float32 on the
+// 32 tile, float64 above 85 px)
+int refine64_is_f64(int refine, bool* f64) {
+    if (refine != SPX_REFINE_DEFAULT && refine != SPX_REFINE_F64)
+        return fail(SPX_E_ARG, "refine must be SPX_REFINE_DEFAULT or SPX_REFINE_F64");
+    *f64 = refine == SPX_REFINE_F64 || spx::kRefine64DefaultF64;
     return 0;
 }
 
@@ -237,6 +247,7 @@ struct PairArgs {
     int ny, nx, U, cc_type;
     const float* ktab;
     const float* ktab_f32;       // for the eight-wave 64-tile kernel (pair_tables_for)
+    bool refine_f64;             // 64 tile: the float64-refine form of the four-wave kernel (`ktab` is then float64)
     double* out;
     int32_t* status;
     float* ws;
@@ -244,16 +255,30 @@ struct PairArgs {
 };
 
 // One pair-mode kernel instance: `launch` false only raises its LDS limit (spx_prepare).
-template <int WB, bool FOLD, typename TIn, int DBG = 0>
-int run_pair64(DeviceTables* t, const TIn* ref, const TIn* img, const PairArgs& a, bool launch) {
+template <int WB, bool FOLD, typename TIn, int DBG, typename R>
+int run_pair64_as(DeviceTables* t, const TIn* ref, const TIn* img, const PairArgs& a, bool launch) {
     const int lds = spx::Lds<2>::total(16 * WB);
-    auto kern = spx::pair_kernel<2, WB, DBG, FOLD, TIn>;
+    auto kern = spx::pair_kernel<2, WB, DBG, FOLD, TIn, R>;
     int rc = allow_lds(t, kern, lds);
     if (rc || !launch) return rc;
     hipLaunchKernelGGL(kern, dim3(grid_for(t, a.nbatch)), dim3(spx::kThreads), lds, a.s, ref, img,
                        a.nbatch, a.ny, a.nx, a.U, a.cc_type, t->tw[TILE64], a.ktab, a.out, a.status);
     SPX_HIP(hipGetLastError());
     return 0;
+}
+// The float64-refine form exists for the product instances with a refine stage (DBG = 0, WB > 0); without
+// `launch` (spx_prepare) BOTH forms get their LDS limit raised, so either may be launched inside a capture.
+template <int WB, bool FOLD, typename TIn, int DBG = 0>
+int run_pair64(DeviceTables* t, const TIn* ref, const TIn* img, const PairArgs& a, bool launch) {
+    if constexpr (DBG == 0 && WB > 0) {
+        if (!launch) {
+            const int rc = run_pair64_as<WB, FOLD, TIn, DBG, spx::RefineF64>(t, ref, img, a, false);
+            if (rc) return rc;
+        } else if (a.refine_f64) {
+            return run_pair64_as<WB, FOLD, TIn, DBG, spx::RefineF64>(t, ref, img, a, true);
+        }
+    }
+    return run_pair64_as<WB, FOLD, TIn, DBG, spx::RefineF32>(t, ref, img, a, launch);
 }
 // the same tile on eight waves per pair (spx_kernels8.h; cutouts up to 64 px, no fold path)
 template <int WB, typename TIn, int DBG = 0>
@@ -314,7 +339,7 @@ int run_pair_wb(DeviceTables* t, Tile tile, bool fold, const TIn* ref, const TIn
                 const int rc = run_pair64_w8<WB, TIn>(t, ref, img, a, false);
                 return rc ? rc : run_pair64<WB, false, TIn>(t, ref, img, a, false);
             }
-            if (pair64_waves() == 8) return run_pair64_w8<WB, TIn>(t, ref, img, a, true);
+            if (pair64_waves() == 8 && !a.refine_f64) return run_pair64_w8<WB, TIn>(t, ref, img, a, true);
         }
         return run_pair64<WB, false, TIn>(t, ref, img, a, launch);
     default: return run_pair192<WB, TIn>(t, ref, img, a, launch);
@@ -450,10 +475,12 @@ int run_disp5_general(DeviceTables* t, const TIn* ref, const TIn* im4, const Dis
 
 template <typename TIn>
 int xcorr_refine(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx, int upsample,
-                 int cc_type, double* out_dxdy, int32_t* out_status, void* workspace,
+                 int cc_type, int refine, double* out_dxdy, int32_t* out_status, void* workspace,
                  size_t workspace_bytes, void* stream) {
     if (nbatch < 0 || (nbatch > 0 && (!ref || !img || !out_dxdy)))
         return fail(SPX_E_ARG, "null pointer or negative batch");
+    bool refine_f64 = false;
+    if (int rr = refine64_is_f64(refine, &refine_f64)) return rr;
     if (ny < 5 || nx < 5 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
         return fail(SPX_E_SHAPE, "pair mode supports cutouts of 5..682 pixels per side");
     const int wb = spx::host::window_blocks(upsample);
@@ -465,7 +492,7 @@ int xcorr_refine(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
     DeviceTables* t = nullptr;
     int rc = current_tables(&t);
     if (rc) return rc;
-    PairArgs a;
+    PairArgs a = {};
     a.nbatch = nbatch; a.ny = ny; a.nx = nx; a.U = upsample; a.cc_type = cc_type;
     a.out = out_dxdy; a.status = out_status;
     a.ws = reinterpret_cast<float*>(workspace);
@@ -485,7 +512,9 @@ int xcorr_refine(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
         lk.enter_launch(t);
         return run_pair_general_wb<TIn>(t, wb, ref, img, a, C, tw, true);
     }
-    rc = pair_tables_for(t, tile, upsample, &a.ktab, &a.ktab_f32);
+    // the eight-wave A/B kernel has no float64 form: a float64-refine call takes the four-wave kernel
+    a.refine_f64 = refine_f64 && tile == TILE64;
+    rc = pair_tables_for(t, tile, upsample, a.refine_f64, &a.ktab, &a.ktab_f32);
     if (rc) return rc;
     lk.enter_launch(t);
     return run_pair<TIn>(t, wb, tile, ny > 64 || nx > 64, ref, img, a, true);
@@ -596,8 +625,9 @@ int spx_prepare(int upsample) {
         std::lock_guard<std::mutex> gl(g_mu);
         for (int k = 0; k < NUM_TILES; ++k) {
             const float* kt = nullptr;
-            const float* kt32 = nullptr;
-            if ((rc = pair_tables_for(t, (Tile)k, upsample, &kt, &kt32))) return rc;
+            const float* kt32 = nullptr;        // both refine forms of the 64 tile: no allocation in a later call
+            if ((rc = pair_tables_for(t, (Tile)k, upsample, false, &kt, &kt32))) return rc;
+            if ((Tile)k == TILE64 && (rc = pair_tables_for(t, TILE64, upsample, true, &kt, &kt32))) return rc;
         }
     }
     for (int k = 0; k < NUM_TILES; ++k) {
@@ -681,13 +711,25 @@ size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int nee
 int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
                          int upsample, int cc_type, double* out_dxdy, int32_t* out_status,
                          void* workspace, size_t workspace_bytes, void* stream) {
-    return xcorr_refine<float>(ref, img, nbatch, ny, nx, upsample, cc_type, out_dxdy, out_status,
+    return xcorr_refine<float>(ref, img, nbatch, ny, nx, upsample, cc_type, SPX_REFINE_DEFAULT, out_dxdy,
+                               out_status, workspace, workspace_bytes, stream);
+}
+int spx_xcorr_refine_ex_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
+                            int upsample, int cc_type, int refine, double* out_dxdy, int32_t* out_status,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    return xcorr_refine<float>(ref, img, nbatch, ny, nx, upsample, cc_type, refine, out_dxdy, out_status,
                                workspace, workspace_bytes, stream);
 }
 int spx_xcorr_refine_f64(const double* ref, const double* img, int64_t nbatch, int ny, int nx,
                          int upsample, int cc_type, double* out_dxdy, int32_t* out_status,
                          void* workspace, size_t workspace_bytes, void* stream) {
-    return xcorr_refine<double>(ref, img, nbatch, ny, nx, upsample, cc_type, out_dxdy, out_status,
+    return xcorr_refine<double>(ref, img, nbatch, ny, nx, upsample, cc_type, SPX_REFINE_DEFAULT, out_dxdy,
+                                out_status, workspace, workspace_bytes, stream);
+}
+int spx_xcorr_refine_ex_f64(const double* ref, const double* img, int64_t nbatch, int ny, int nx,
+                            int upsample, int cc_type, int refine, double* out_dxdy, int32_t* out_status,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    return xcorr_refine<double>(ref, img, nbatch, ny, nx, upsample, cc_type, refine, out_dxdy, out_status,
                                 workspace, workspace_bytes, stream);
 }
 
@@ -701,12 +743,13 @@ int spx_diag_pair_phase(const float* ref, const float* img, int64_t nbatch, int 
     DeviceTables* t = nullptr;
     int rc = current_tables(&t);
     if (rc) return rc;
-    PairArgs a;
+    PairArgs a = {};
     a.nbatch = nbatch; a.ny = ny; a.nx = nx; a.U = 10; a.cc_type = 0; a.out = out_dxdy;
     a.status = out_status; a.ws = nullptr; a.s = reinterpret_cast<hipStream_t>(stream);
     {
         std::lock_guard<std::mutex> gl(g_mu);
-        rc = pair_tables_for(t, TILE64, 10, &a.ktab, &a.ktab_f32);
+        a.refine_f64 = false;
+        rc = pair_tables_for(t, TILE64, 10, false, &a.ktab, &a.ktab_f32);
     }
     if (rc) return rc;
     const bool fold = ny > 64 || nx > 64;
@@ -732,7 +775,7 @@ int spx_diag_pair128_phase(const float* ref, const float* img, int64_t nbatch, i
     int rc = current_tables(&t);
     if (rc) return rc;
     if (workspace_bytes < workspace_bytes_big(nbatch)) return fail(SPX_E_WORKSPACE, "workspace");
-    PairArgs a;
+    PairArgs a = {};
     a.nbatch = nbatch; a.ny = ny; a.nx = nx; a.U = 20; a.cc_type = 0; a.out = out_dxdy;
     a.status = out_status; a.ws = reinterpret_cast<float*>(workspace);
     a.s = reinterpret_cast<hipStream_t>(stream);

@@ -1312,15 +1312,14 @@ struct RefineF64 {
     static SPX_DEVICE V4 mma(S a, S b, V4 c) { return rt::mfma_f64_16x16x4(a, b, c); }
     static SPX_DEVICE int drow(int lk, int r) { return lk + 4 * r; }
 };
+// pair_kernel takes the arithmetic as a template parameter and the library holds both forms (the caller
+// chooses per call: SPX_REFINE_* in include/subpixal_hip.h).  SPX_REFINE64_F64 only says what SPX_REFINE_DEFAULT
+// means for the 64 tile: float32 -- measured 14 % faster at 64 px / upsample 10 and 18x inside the 1e-3 px
+// tolerance there (profiles/r03/refine64_throughput_ab.txt) -- unless a build is made with -DSPX_REFINE64_F64=1.
 #ifndef SPX_REFINE64_F64
 #define SPX_REFINE64_F64 0
 #endif
-#if SPX_REFINE64_F64
-typedef RefineF64 Refine64;                      // the 64 tile's refine (pair_kernel, incl. the fold path)
-#else
-typedef RefineF32 Refine64;
-#endif
-constexpr bool kRefine64F64 = SPX_REFINE64_F64 != 0;     // which table the host hands that kernel (spx_tables.h)
+constexpr bool kRefine64DefaultF64 = SPX_REFINE64_F64 != 0;
 
 template <int WB, typename R = RefineF32> struct FineTables {
     typedef typename R::V4 V4;
@@ -1411,55 +1410,98 @@ SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB, R>& ft,
     }
     // stage 2: F^T[b][a] = sum_mx'' sgn_x K_cx[b][mx''] G^T[mx''][a]; accumulator register
     // r of tile t is B-operand row k' = lane>>4 for mx'' = 16 t + R::drow(k', r) - 32.
-    V4 f[WB][WB];
-#pragma unroll
-    for (int bb = 0; bb < WB; ++bb)
-#pragma unroll
-        for (int ab = 0; ab < WB; ++ab) f[bb][ab] = R::zero();
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        V4 ka[WB];
-#pragma unroll
-        for (int bb = 0; bb < WB; ++bb) ka[bb] = ft.x(bb, t);
+    const S scale = (S)0.5 / (S)(L::P * L::P);
+    // where block (bb, ab) of this class's window goes: one window per class, which the reader adds in fixed
+    // order (fine_value), or -- large windows -- ONE buffer that the classes add to in fixed order
+    auto put = [&](int bb, int ab, const V4& fv, int c) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = lxc + 16 * t + R::drow(lk, r) - 32;
-            const S sgn = (cx && ((m >> 6) & 1)) ? (S)-1 : (S)1;
-#pragma unroll
-            for (int bb = 0; bb < WB; ++bb)
-#pragma unroll
-                for (int ab = 0; ab < WB; ++ab)
-                    f[bb][ab] = R::mma(sgn * ka[bb][r], acc[ab][t][r], f[bb][ab]);
+            const int b = bb * 16 + R::drow(lk, r), a = ab * 16 + lj;
+            const float val = (float)(fv[r] * scale);
+            if constexpr (L::fb_count(W) == C * C) fbuf[wave * W * W + b * W + a] = val;
+            else { if (c == 0) fbuf[b * W + a] = val; else fbuf[b * W + a] += val; }
         }
-    }
-    const S scale = (S)0.5 / (S)(L::P * L::P);
-    if constexpr (L::fb_count(W) == C * C) {
-        // one window per class; the reader adds the four in fixed order (fine_value)
-        float* mine = fbuf + wave * W * W;
+    };
+    if constexpr (sizeof(S) == 4) {
+        V4 f[WB][WB];
 #pragma unroll
         for (int bb = 0; bb < WB; ++bb)
 #pragma unroll
-            for (int ab = 0; ab < WB; ++ab)
+            for (int ab = 0; ab < WB; ++ab) f[bb][ab] = R::zero();
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    mine[(bb * 16 + R::drow(lk, r)) * W + ab * 16 + lj] = (float)(f[bb][ab][r] * scale);
-        rt::block_sync_lds();
-    } else {
-        // large windows: accumulate the 4 classes in fixed order into one buffer
-        for (int c = 0; c < C * C; ++c) {
-            if (wave == c) {
+        for (int t = 0; t < 4; ++t) {
+            V4 ka[WB];
+#pragma unroll
+            for (int bb = 0; bb < WB; ++bb) ka[bb] = ft.x(bb, t);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = lxc + 16 * t + R::drow(lk, r) - 32;
+                const S sgn = (cx && ((m >> 6) & 1)) ? (S)-1 : (S)1;
 #pragma unroll
                 for (int bb = 0; bb < WB; ++bb)
 #pragma unroll
                     for (int ab = 0; ab < WB; ++ab)
+                        f[bb][ab] = R::mma(sgn * ka[bb][r], acc[ab][t][r], f[bb][ab]);
+            }
+        }
+        if constexpr (L::fb_count(W) == C * C) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int b = bb * 16 + R::drow(lk, r), a = ab * 16 + lj;
-                            const float val = (float)(f[bb][ab][r] * scale);
-                            if (c == 0) fbuf[b * W + a] = val; else fbuf[b * W + a] += val;
-                        }
+            for (int bb = 0; bb < WB; ++bb)
+#pragma unroll
+                for (int ab = 0; ab < WB; ++ab) put(bb, ab, f[bb][ab], 0);
+            rt::block_sync_lds();
+        } else {
+            for (int c = 0; c < C * C; ++c) {
+                if (wave == c) {
+#pragma unroll
+                    for (int bb = 0; bb < WB; ++bb)
+#pragma unroll
+                        for (int ab = 0; ab < WB; ++ab) put(bb, ab, f[bb][ab], c);
+                }
+                rt::block_sync_lds();
+            }
+        }
+    } else {
+        // float64: one block of fine x offsets at a time (as fine_window128), so that only WB result tiles of
+        // eight registers are live beside stage 1's 4 WB (four window blocks: 160 registers instead of 256).
+        // Large windows: the classes take turns block by block, still in fixed order.
+        auto block = [&](int bb, V4 (&f)[WB]) {
+#pragma unroll
+            for (int ab = 0; ab < WB; ++ab) f[ab] = R::zero();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const V4 ka = ft.x(bb, t);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = lxc + 16 * t + R::drow(lk, r) - 32;
+                    const S sgn = (cx && ((m >> 6) & 1)) ? (S)-1 : (S)1;
+#pragma unroll
+                    for (int ab = 0; ab < WB; ++ab) f[ab] = R::mma(sgn * ka[r], acc[ab][t][r], f[ab]);
+                }
+            }
+        };
+        if constexpr (L::fb_count(W) == C * C) {
+#pragma unroll
+            for (int bb = 0; bb < WB; ++bb) {
+                V4 f[WB];
+                block(bb, f);
+#pragma unroll
+                for (int ab = 0; ab < WB; ++ab) put(bb, ab, f[ab], 0);
             }
             rt::block_sync_lds();
+        } else {
+            for (int c = 0; c < C * C; ++c) {
+                if (wave == c) {
+#pragma unroll
+                    for (int bb = 0; bb < WB; ++bb) {
+                        V4 f[WB];
+                        block(bb, f);
+#pragma unroll
+                        for (int ab = 0; ab < WB; ++ab) put(bb, ab, f[ab], c);
+                    }
+                }
+                rt::block_sync_lds();
+            }
         }
     }
 }
@@ -1614,7 +1656,7 @@ SPX_DEVICE PeakResult peak_fit_wave0(unsigned char* lds_scr, int imax, int jmax,
 // Pair kernel: one workgroup per (ref, img) pair.
 //   out[2*pair + {0,1}] = (dx, dy) float64, status[pair]
 // ---------------------------------------------------------------------------
-template <int C, int WB, int DBG = 0, bool FOLD = false, typename TIn = float>
+template <int C, int WB, int DBG = 0, bool FOLD = false, typename TIn = float, typename R = RefineF32>
 SPX_DEVICE void pair_body(const TIn* __restrict__ ref, const TIn* __restrict__ img,
                           int ny, int nx, int U, int cc_type, const cf* __restrict__ tw_g,
                           const float* __restrict__ ktab, double* __restrict__ out,
@@ -1641,8 +1683,8 @@ SPX_DEVICE void pair_body(const TIn* __restrict__ ref, const TIn* __restrict__ i
     // the refine stage's constant operands: issue the loads now, use them after the arg-max -- and BEFORE the
     // warm-up below: vmcnt counts in issue order, so a wait for the tables must not include the warm-up's
     // trip to HBM (+1.3 %, profiles/r03/variants_*.txt)
-    FineTables<(WB > 0 ? WB : 1), Refine64> ft;
-    if constexpr (WB > 0) load_fine_tables<C, WB, Refine64>(ft, ktab, rot);
+    FineTables<(WB > 0 ? WB : 1), R> ft;
+    if constexpr (WB > 0) load_fine_tables<C, WB, R>(ft, ktab, rot);
     // pull the next pair into L2 while this one is in its tail (issuing it before the transforms instead
     // was measured 2 % slower)
     if constexpr (sizeof(TIn) == 4) if (next_ref) warm = warm_next_pair(next_ref, next_img);
@@ -1675,7 +1717,7 @@ SPX_DEVICE void pair_body(const TIn* __restrict__ ref, const TIn* __restrict__ i
         int imax = 0, jmax = 0;
         bool inside = false;
         for (int iter = 0; iter < 4; ++iter) {
-            fine_window<C, (WB > 0 ? WB : 1), Refine64>(lds, ft, ny, nx, qyc, qxc, rot);
+            fine_window<C, (WB > 0 ? WB : 1), R>(lds, ft, ny, nx, qyc, qxc, rot);
             clk.tick(12);
             if constexpr (DBG == 12) { if (tid == 0) out[0] = (double)fine_value<C, W>(lds, 0, 0); return; }
             // arg-max over the part of the window inside the virtual image: every wave scans
@@ -1739,7 +1781,7 @@ SPX_DEVICE void pair_body(const TIn* __restrict__ ref, const TIn* __restrict__ i
     clk.tick(14);
 }
 
-template <int C, int WB, int DBG = 0, bool FOLD = false, typename TIn = float>
+template <int C, int WB, int DBG = 0, bool FOLD = false, typename TIn = float, typename R = RefineF32>
 SPX_TKERNEL(256) void pair_kernel(const TIn* __restrict__ ref, const TIn* __restrict__ img,
                                   int64_t nbatch, int ny, int nx, int U, int cc_type,
                                   const cf* __restrict__ tw_g, const float* __restrict__ ktab,
@@ -1761,7 +1803,7 @@ SPX_TKERNEL(256) void pair_kernel(const TIn* __restrict__ ref, const TIn* __rest
     const double inv_u = rt::read_lane(1.0 / (double)U, 0);
     for (int64_t p = first_item(rt::block_id(), step); p < nbatch; p += step) {
         const bool more = full && (p + step < nbatch);
-        pair_body<C, WB, DBG, FOLD, TIn>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, tw_g, ktab,
+        pair_body<C, WB, DBG, FOLD, TIn, R>(ref + p * stride, img + p * stride, ny, nx, U, cc_type, tw_g, ktab,
                               out + 2 * p, status ? status + p : nullptr, lds, clk,
                               more ? ref + (p + step) * stride : nullptr,
                               more ? img + (p + step) * stride : nullptr, warm, fit_wave, inv_u);

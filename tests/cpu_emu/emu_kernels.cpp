@@ -29,10 +29,13 @@ extern "C" int emu_lds_bytes(int U) {
 #if EMU_PART == 4
 int64_t g_grid = 0;            // 0: one workgroup per item; else grid-stride over the batch
 extern "C" void emu_set_grid(int64_t g) { g_grid = g; }
+int g_refine64 = 0;            // the 64 tile's refine: 0 float32 (the product default), 1 float64 (SPX_REFINE_F64)
+extern "C" void emu_set_refine64(int v) { g_refine64 = v; }
 // the kernels' workgroup -> first item mapping (spx_kernels.h), for the bijection test
 extern "C" int64_t emu_first_item(int64_t b, int64_t nwg) { return first_item(b, nwg); }
 #else
 extern int64_t g_grid;
+extern int g_refine64;
 #endif
 
 // ---------------------------------------------------------------------------
@@ -40,27 +43,35 @@ extern int64_t g_grid;
 // path for 65..85 px; period 192 for 86..128 px), for float32 and float64 inputs
 // ---------------------------------------------------------------------------
 #if EMU_PART == 1 || EMU_PART == 2
-template <bool FOLD, typename TIn>
-static int emu_pair64(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
-                      int U, int cc_type, double* out, int* status) {
+// R: the refine stage's arithmetic (spx_kernels.h RefineF32 / RefineF64), each with its own table form
+template <bool FOLD, typename TIn, typename R>
+static int emu_pair64_as(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
+                         int U, int cc_type, double* out, int* status) {
+    constexpr bool kF64 = sizeof(typename R::S) == 8;
     const int wb = host::window_blocks(U);
     std::vector<float> tw = host::make_twiddles(128);
     std::vector<float> kt;
-    std::vector<double> ktd;                      // the float64 refine's tables (spx::kRefine64F64)
-    if (wb > 0) { if (kRefine64F64) ktd = host::make_ktab_f64(128, U, 16 * wb); else kt = host::make_ktab(128, U, 16 * wb); }
+    std::vector<double> ktd;
+    if (wb > 0) { if (kF64) ktd = host::make_ktab_f64(128, U, 16 * wb); else kt = host::make_ktab(128, U, 16 * wb); }
     const cf* twp = reinterpret_cast<const cf*>(tw.data());
-    const float* ktp = wb <= 0 ? nullptr : kRefine64F64 ? reinterpret_cast<const float*>(ktd.data()) : kt.data();
+    const float* ktp = wb <= 0 ? nullptr : kF64 ? reinterpret_cast<const float*>(ktd.data()) : kt.data();
     auto run = [&](auto fn) {
         rt::launch(g_grid > 0 && g_grid < nbatch ? g_grid : nbatch, kThreads, fn, Lds<2>::total(16 * wb));
     };
     switch (wb) {
-    case 0: run([&] { pair_kernel<2, 0, 0, FOLD, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
-    case 1: run([&] { pair_kernel<2, 1, 0, FOLD, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
-    case 2: run([&] { pair_kernel<2, 2, 0, FOLD, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
-    case 3: run([&] { pair_kernel<2, 3, 0, FOLD, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
-    default: run([&] { pair_kernel<2, 4, 0, FOLD, TIn>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 0: run([&] { pair_kernel<2, 0, 0, FOLD, TIn, R>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 1: run([&] { pair_kernel<2, 1, 0, FOLD, TIn, R>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 2: run([&] { pair_kernel<2, 2, 0, FOLD, TIn, R>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    case 3: run([&] { pair_kernel<2, 3, 0, FOLD, TIn, R>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
+    default: run([&] { pair_kernel<2, 4, 0, FOLD, TIn, R>(ref, img, nbatch, ny, nx, U, cc_type, twp, ktp, out, status); }); break;
     }
     return 0;
+}
+template <bool FOLD, typename TIn>
+static int emu_pair64(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
+                      int U, int cc_type, double* out, int* status) {
+    return g_refine64 ? emu_pair64_as<FOLD, TIn, RefineF64>(ref, img, nbatch, ny, nx, U, cc_type, out, status)
+                      : emu_pair64_as<FOLD, TIn, RefineF32>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
 }
 
 // the 64 tile on eight waves per pair (spx_kernels8.h)

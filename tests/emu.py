@@ -38,6 +38,12 @@ def set_grid(g):
     lib().emu_set_grid(ctypes.c_int64(g))
 
 
+def set_refine64(v):
+    """refine arithmetic of the 64 tile and its fold path in pair(): 0 float32 (the product's default), 1 float64
+    (what SPX_REFINE_F64 selects through the C-ABI)"""
+    lib().emu_set_refine64(int(v))
+
+
 def set_disp5_packed(v):
     """64-tile reference-mode kernel: 0 round 2's, 1 the product's rule (the five-transform kernel of
     spx_kernels5.h up to 64 px, the eight-transform one on the fold path), 2 always the five-transform one"""

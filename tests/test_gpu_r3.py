@@ -152,3 +152,31 @@ def test_five_transform_reference_mode_kernel_for_every_cc_type(spx):
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert 'five-transform kernel OK' in out.stdout
+
+
+@pytest.mark.gpu
+def test_float64_refine_through_the_c_abi():
+    """spx_xcorr_refine_ex_* with SPX_REFINE_F64 (cc.xcorr_refine_batch(refine='float64')): the 64 tile and its
+    fold path accumulate the refine in float64 -- measured 1.2e-5 / 2.3e-5 px (64 px) and 1.4e-5 / 2.7e-5 px
+    (80 px) against the float64 definition at upsample 10 / 20 where the default is at 5.5e-5 ... 1.3e-4
+    (profiles/r03/refine_precision*.txt).  Families without a second form return the same bits either way."""
+    from subpixal_amd import cc
+    for n, bound in ((64, 6e-5), (80, 6e-5)):
+        ref, img, _ = datagen.pair_batch(20261005 + n, 24, n)
+        for up in (10, 20):
+            exp, est = orc.xcorr_refine_batch(ref, img, up)
+            got64, st64 = cc.xcorr_refine_batch(ref, img, upsample=up, return_status=True, refine='float64')
+            got32, st32 = cc.xcorr_refine_batch(ref, img, upsample=up, return_status=True)
+            assert np.array_equal(st64, est) and np.array_equal(st32, est)
+            d64, d32 = np.abs(got64 - exp).max(), np.abs(got32 - exp).max()
+            assert d64 < bound, (n, up, d64)
+            assert d32 < 2e-4, (n, up, d32)                  # the default's bound, unchanged
+            assert d64 < d32, (n, up, d64, d32)
+    for n in (32, 96):                                       # float32 only / float64 only: one form each
+        ref, img, _ = datagen.pair_batch(7, 8, n)
+        a = cc.xcorr_refine_batch(ref, img, upsample=10, refine='float64')
+        b = cc.xcorr_refine_batch(ref, img, upsample=10)
+        assert np.array_equal(a, b), n
+    with pytest.raises(ValueError):
+        cc.xcorr_refine_batch(ref, img, upsample=10, refine='float128')
+

@@ -35,6 +35,28 @@ def test_pair_mode_grid_stride_pipeline():
     assert np.array_equal(st, est)
 
 
+def test_pair_mode_float64_refine():
+    """The 64 tile and its fold path with the refine stage's matrix products accumulated in float64
+    (spx_kernels.h RefineF64, make_ktab_f64: what SPX_REFINE_F64 selects): same statuses, and closer to
+    the float64 definition than the float32 form on the same pairs.  A wrong table order or result-row
+    map (v_mfma_f64_16x16x4_f64 puts row lk + 4 r where the float32 one puts 4 lk + r) shows as whole pixels."""
+    try:
+        for n in (64, 80):
+            ref, img, _ = datagen.pair_batch(11 + n, 3, n)
+            for up in (10, 20):
+                exp, est = orc.xcorr_refine_batch(ref, img, up)
+                emu.set_refine64(0)
+                got32, st32 = emu.pair(ref, img, up)
+                emu.set_refine64(1)
+                got64, st64 = emu.pair(ref, img, up)
+                d32, d64 = np.abs(got32 - exp).max(), np.abs(got64 - exp).max()
+                assert np.array_equal(st64, est) and np.array_equal(st32, est)
+                assert d64 < 3e-5, (n, up, d64)
+                assert d64 < d32, (n, up, d64, d32)
+    finally:
+        emu.set_refine64(0)
+
+
 def test_pair_mode_eight_wave_kernel():
     """spx_kernels8.h (round 3 A/B, SPX_PAIR64_WAVES=8): 16 mod-4 classes in half-waves, recombined into
     the four parity planes -- same results as the four-wave kernel to float32 rounding, ragged shapes,

@@ -33,6 +33,13 @@ timeout -k 10 300 python tools/phase_cycles128.py > $O/phase_cycles128.txt 2>&1 
 step "rates"; for cfg in "128 20" "96 10" "80 10" "32 10"; do set -- $cfg
   $B --tile $1 --upsample $2 --no-cpu-baseline --no-reference-mode 2>/dev/null > $O/bench_$1_u$2.json || exit 1
 done
+# the float64 form of the 64 tile's refine (SPX_REFINE_F64): rates next to the default's, and both forms' distance
+# from the float64 definition
+for cfg in "64 10" "64 20" "80 10"; do set -- $cfg
+  $B --tile $1 --upsample $2 --refine float64 --no-cpu-baseline --no-reference-mode 2>/dev/null > $O/bench_$1_u$2_refine_f64.json || exit 1
+done
+$B --tile 64 --upsample 20 --no-cpu-baseline --no-reference-mode 2>/dev/null > $O/bench_64_u20.json || exit 1
+timeout -k 10 500 python tools/refine_precision.py --count 48 --budget 400 2>/dev/null > $O/refine_precision.txt
 python tools/bench_disp5.py 2>/dev/null > $O/disp5.txt
 python tools/bench_shapes.py 2>/dev/null > $O/shapes.txt
 python tools/align_catalog.py 2>/dev/null > $O/align_catalog.txt

@@ -9,7 +9,7 @@ are counted once, which is what a pair normally executes.  STATIC: code of branc
 take (ragged staging instantiations, normalisation) is counted too -- an over-count; the dynamic
 figure comes from the SQ_INSTS_VALU_* counter passes (tools/gpu_sq_flops.sh).
 
-    python tools/kernel_flops.py 'pair_kernel<2, 1, 0, false, float>' [waves_per_pair]
+    python tools/kernel_flops.py 'pair_kernel<2, 1, 0, false, float, spx::RefineF32>' [waves_per_pair]
     python tools/kernel_flops.py --json OUT.json      # the table bench.py reads (all bench kernels)
 """
 import json
@@ -73,8 +73,8 @@ def census(txt, index, want, waves):
 # the kernel instances bench.py can time: (family key, WB) -> (instance name, waves per pair)
 BENCH_KERNELS = {
     '32:1': ('pair32_kernel<1, float>', 1),
-    '64:1': ('pair_kernel<2, 1, 0, false, float>', 4),
-    '64fold:1': ('pair_kernel<2, 1, 0, true, float>', 4),
+    '64:1': ('pair_kernel<2, 1, 0, false, float, spx::RefineF32>', 4),
+    '64fold:1': ('pair_kernel<2, 1, 0, true, float, spx::RefineF32>', 4),
     '64w8:1': ('pair8_kernel<1, 0, float>', 8),
 }
 
@@ -100,7 +100,7 @@ def main():
         json.dump(out, open(sys.argv[2], 'w'), indent=1)
         print(json.dumps(out, indent=1))
         return
-    want = sys.argv[1] if len(sys.argv) > 1 else 'pair_kernel<2, 1, 0, false, float>'
+    want = sys.argv[1] if len(sys.argv) > 1 else 'pair_kernel<2, 1, 0, false, float, spx::RefineF32>'
     waves = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     c = census(txt, index, want, waves)
     assert c, 'kernel not found: ' + want

@@ -1,11 +1,12 @@
 #!/usr/bin/env python
 """Where does pair mode's distance from the float64 definition come from: the refine stage's arithmetic
-or the float32 transforms?  Same noise-free spots (SURVEY.md 8(d)'s parity set: sigma ~ U(4,6) px,
-shifts ~ U(-3,3) px) through the kernel families that refine in float32 (64 tile, its fold path) and
-the one that refines in float64 (period 192), against oracle.xcorr_refine_batch (float64 throughout),
-per upsample factor.  Test infrastructure: the oracle is the checker here, nothing is timed.
+or the float32 transforms?  Same noise-free spots (SURVEY.md 8(d)'s parity set: sigma ~ U(4,6) px, 3..4 px on
+the 32 tile, shifts ~ U(-3,3) px) through every kernel family up to 128 px, in both forms of the refine
+where a family has two (refine='default' / 'float64' = SPX_REFINE_DEFAULT / SPX_REFINE_F64), against
+oracle.xcorr_refine_batch (float64 throughout), per upsample factor.
+Test infrastructure: the oracle is the checker here, nothing is timed.
 
-    python tools/refine_precision.py [--count 128] [--budget 400]
+    python tools/refine_precision.py [--count 48] [--budget 600]
 """
 import argparse
 import os
@@ -21,26 +22,31 @@ import subpixal_amd as spx                             # noqa: E402
 from oracle import subpixal_oracle as orc              # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument('--count', type=int, default=128)
-ap.add_argument('--budget', type=float, default=400.0, help='seconds')
-ap.add_argument('--refine64', default='float32', choices=['float32', 'float64'],
-                help='what the loaded library\'s 64-tile kernel refines in (labels only: a -DSPX_REFINE64_F64=1 build is float64)')
+ap.add_argument('--count', type=int, default=48)
+ap.add_argument('--budget', type=float, default=600.0, help='seconds')
 a = ap.parse_args()
 
-FAMILIES = [(64, '64 tile, %s refine' % a.refine64), (80, 'fold path, %s refine' % a.refine64),
-            (96, 'period 192, float64 refine'), (128, 'period 192, float64 refine')]
+# (cutout side, family, what each refine value means there)
+FAMILIES = [(32, '32 tile', {'default': 'float32', 'float64': 'float32 (no other form)'}),
+            (64, '64 tile', {'default': 'float32', 'float64': 'float64'}),
+            (80, 'fold path', {'default': 'float32', 'float64': 'float64'}),
+            (96, 'period 192', {'default': 'float64 (its only form)'}),
+            (128, 'period 192', {'default': 'float64 (its only form)'})]
 UPS = [1, 2, 10, 20, 28, 40]
 t0 = time.time()
 print('pairs per cell: %d (float32 cutouts, noise-free); |kernel - float64 oracle| in px' % a.count)
-print('%-4s %-28s %4s %10s %10s %10s' % ('n', 'family', 'U', 'median', '99 %', 'max'))
-for n, fam in FAMILIES:
-    ref, img, _ = datagen.pair_batch(20261005 + n, a.count, n, sigma_lo=4.0, sigma_hi=6.0)
+print('%-4s %-11s %-26s %4s %10s %10s %10s' % ('n', 'family', 'refine arithmetic', 'U', 'median', '99 %', 'max'))
+for n, fam, forms in FAMILIES:
+    ref, img, _ = datagen.pair_batch(20261005 + n, a.count, n)
     for up in UPS:
         if time.time() - t0 > a.budget:
             print('time budget reached'); sys.exit(0)
-        got, st = spx.xcorr_refine_batch(ref, img, upsample=up, return_status=True)
         exp, est = orc.xcorr_refine_batch(ref, img, upsample=up)
-        got = np.asarray(got); st = np.asarray(st)
-        d = np.abs(got - exp).max(axis=1)
-        print('%-4d %-28s %4d %10.2e %10.2e %10.2e   status equal: %s' % (
-            n, fam, up, np.median(d), np.quantile(d, 0.99), d.max(), bool(np.array_equal(st, est))), flush=True)
+        for refine, what in forms.items():
+            if refine == 'float64' and n <= 32 and up != 10:
+                continue                                   # one line is enough to show it is the same kernel
+            got, st = spx.xcorr_refine_batch(ref, img, upsample=up, return_status=True, refine=refine)
+            d = np.abs(np.asarray(got) - exp).max(axis=1)
+            print('%-4d %-11s %-26s %4d %10.2e %10.2e %10.2e   status equal: %s' % (
+                n, fam, what, up, np.median(d), np.quantile(d, 0.99), d.max(),
+                bool(np.array_equal(np.asarray(st), est))), flush=True)
