@@ -1422,7 +1422,10 @@ SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB, R>& ft,
             else { if (c == 0) fbuf[b * W + a] = val; else fbuf[b * W + a] += val; }
         }
     };
-    if constexpr (sizeof(S) == 4) {
+    // all WB x WB result tiles live at once: float32 always; float64 up to two window blocks (0 spills, and at
+    // upsample 20 measured 6.0 ms per 1e5 pairs against 7.6 ms for the block-at-a-time form below, whose table
+    // reads from L2 sit in a serial loop: profiles/r03/refine64_throughput_ab.txt, bench_64_u20_refine_f64.json)
+    if constexpr (sizeof(S) == 4 || WB <= 2) {
         V4 f[WB][WB];
 #pragma unroll
         for (int bb = 0; bb < WB; ++bb)
@@ -1462,8 +1465,8 @@ SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB, R>& ft,
             }
         }
     } else {
-        // float64: one block of fine x offsets at a time (as fine_window128), so that only WB result tiles of
-        // eight registers are live beside stage 1's 4 WB (four window blocks: 160 registers instead of 256).
+        // float64, three and four window blocks: one block of fine x offsets at a time (as fine_window128), so that
+        // only WB result tiles of eight registers are live beside stage 1's 4 WB (four blocks: 160 registers, not 256).
         // Large windows: the classes take turns block by block, still in fixed order.
         auto block = [&](int bb, V4 (&f)[WB]) {
 #pragma unroll
