@@ -161,9 +161,10 @@ int spx_xcorr_refine_f64(const double* ref, const double* img, int64_t nbatch, i
  *                       float64 above (the period-192 and general paths have only that form).
  *   SPX_REFINE_F64      float64 accumulation on cutouts of 33..85 px as well (the 64 tile and its fold path).
  *                       Measured on one MI355X against the float64 definition, noise-free 4..6-px-sigma spots
- *                       (profiles/r03/refine_precision*.txt): 64 px at upsample 10 / 20 / 40: 1.2e-5 / 2.3e-5 /
+ *                       (profiles/r03/refine_precision.txt): 64 px at upsample 10 / 20 / 40: 1.2e-5 / 2.3e-5 /
  *                       4.5e-5 px instead of 5.5e-5 / 1.3e-4 / 1.3e-4; and 14 % / 21 % fewer pairs per second at
- *                       upsample 10 / 20 (profiles/r03/refine64_throughput_ab.txt).  Both are inside the 1e-3 px
+ *                       upsample 10 / 20 (profiles/r03/bench_64_u10_refine_f64.json, bench_64_u20_refine_f64.json
+ *                       next to bench.json, bench_64_u20.json).  Both are inside the 1e-3 px
  *                       this library promises; the flag buys the margin, not the promise.
  *                       Cutouts up to 32 px per side have no float64 form and are refined in float32 with either
  *                       value; upsample >= 43 on 33..85 px runs with ~50 spilled registers in this form (slower).

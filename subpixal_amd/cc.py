@@ -58,7 +58,7 @@ def xcorr_refine_batch(ref, img, upsample=1, cc_type='CC', return_status=False, 
         default is float32 matrix products on cutouts up to 85 px per side and float64 above; ``'float64'``
         accumulates in float64 on 33..85 px as well: 4-7x closer to the float64 definition (64 px,
         upsample 10: 1.2e-5 instead of 5.5e-5 px) for 14 % fewer pairs per second there -- both well inside
-        the 1e-3 px tolerance (``profiles/r03/refine_precision*.txt``, ``refine64_throughput_ab.txt``).
+        the 1e-3 px tolerance (``profiles/r03/refine_precision.txt``, ``bench_64_u10_refine_f64.json``).
         Cutouts up to 32 px are refined in float32 either way.
 
     Returns ``dxdy [N, 2]`` float64 (torch CUDA tensor if the inputs were
