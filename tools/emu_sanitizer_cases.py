@@ -88,4 +88,26 @@ try:
             assert np.array_equal(st, est) and np.abs(d - e).max() < 1e-4
 finally:
     emu.set_disp5_packed(1)
+# round 3: the float64 form of the 64 tile's refine (spx_kernels.h RefineF64: float64 tables, result rows lk + 4 r,
+# block-at-a-time stage 2 from three window blocks on), ragged shapes and the fold path, several items per workgroup
+emu.set_refine64(1)
+try:
+    for (ny, nx), ups in (((64, 64), (10,) if quick else (10, 20, 28, 43)), ((47, 61), () if quick else (10, 43)),
+                          ((80, 80), () if quick else (10, 28)), ((85, 70), () if quick else (20, 59))):
+        if not ups:
+            continue
+        tx, ty, sg, am = datagen.random_params(13, 3, max(ny, nx))
+        ref = np.stack([datagen.pair_set(ny, nx, tx[k], ty[k], sg[k], am[k])[0] for k in range(3)])
+        img = np.stack([datagen.pair_set(ny, nx, tx[k], ty[k], sg[k], am[k])[1] for k in range(3)])
+        for up in ups:
+            emu.set_grid(2)
+            try:
+                got, st = emu.pair(ref, img, up)
+            finally:
+                emu.set_grid(0)
+            exp, est = orc.xcorr_refine_batch(ref, img, up)
+            print('float64-refine pair %3dx%-3d U=%-2d max |d| %.2e' % (ny, nx, up, float(np.abs(got - exp).max())), flush=True)
+            assert np.array_equal(st, est) and np.abs(got - exp).max() < 1e-4
+finally:
+    emu.set_refine64(0)
 print('sanitizer cases OK')
