@@ -78,7 +78,9 @@ def kernel_name(tile, upsample, refine='default'):
         return 'spx::pair32_kernel<%d, float>' % wb
     if tile <= 85:
         # the default refine arithmetic (float32) of the 64 tile; spx::RefineF64 is the SPX_REFINE_F64 form
-        arith = 'RefineF64' if refine == 'float64' and wb > 0 else 'RefineF32'
+        # the library's default: float32 up to two window blocks (upsample <= 27), float64 from three on
+        f64 = wb > 0 and (refine == 'float64' or (refine == 'default' and wb >= 3))
+        arith = 'RefineF64' if f64 else 'RefineF32'
         return 'spx::pair_kernel<2, %d, 0, %s, float, spx::%s>' % (wb, 'true' if tile > 64 else 'false', arith)
     return 'spx::pair128_kernel<3, %d, 0, float>' % wb
 
@@ -298,7 +300,7 @@ def main():
                     help='skip the reference-mode (cc.find_displacement) block of the N=1 line')
     ap.add_argument('--tile', type=int, default=TILE, help='cutout side (64 = config 2, 128 = config 3)')
     ap.add_argument('--upsample', type=int, default=UPSAMPLE)
-    ap.add_argument('--refine', default='default', choices=['default', 'float64'],
+    ap.add_argument('--refine', default='default', choices=['default', 'float64', 'float32'],
                     help="arithmetic of the refine stage (SPX_REFINE_*): 'float64' = the slower, more precise form of the "
                          "64 tile / fold path; the graded line is the default")
     ap.add_argument('--backend', default='nccl', help="'gloo' + --one-device rehearses the N>1 path on one GPU")
@@ -411,7 +413,7 @@ def main():
         traffic, traffic_src = None, None
         pmc, src = _profile_json(name)
         # (the counter files were taken on the default refine form: a --refine float64 line quotes none of them)
-        counters_apply = args.refine == 'default' or tile <= 32 or tile > 85
+        counters_apply = args.refine == 'default' or tile <= 32 or tile > 85     # (measured with the default)
         if counters_apply and pmc is not None and pmc.get('pairs_per_launch') == n_local and \
                 pmc.get('tile', TILE) == tile and pmc.get('upsample', UPSAMPLE) == ups:
             traffic, traffic_src = pmc['hbm_bytes_per_launch'], src

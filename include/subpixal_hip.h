@@ -99,7 +99,9 @@ extern "C" {
 /* largest cutout side and upsampling factor the kernels accept */
 #define SPX_MAX_SIDE 682
 #define SPX_MAX_UPSAMPLE 59
+#ifndef SPX_MAX_UPSAMPLE_GENERAL      /* (overridable only to MEASURE beyond it: tools/general_precision.py) */
 #define SPX_MAX_UPSAMPLE_GENERAL 39 /* pair mode on cutouts above 128 px (float32 transforms: see spx_xcorr_refine_f32) */
+#endif
 
 int spx_abi_version(void);
 int spx_device_count(void);
@@ -157,21 +159,32 @@ int spx_xcorr_refine_f64(const double* ref, const double* img, int64_t nbatch, i
 /*
  * The same with the arithmetic of the refine stage (the U-times upsampling around the coarse maximum,
  * upsample > 1) chosen by the caller.  The transforms are float32 either way.
- *   SPX_REFINE_DEFAULT  what spx_xcorr_refine_f32 / _f64 do: float32 matrix products up to 85 px per side,
- *                       float64 above (the period-192 and general paths have only that form).
- *   SPX_REFINE_F64      float64 accumulation on cutouts of 33..85 px as well (the 64 tile and its fold path).
- *                       Measured on one MI355X against the float64 definition, noise-free 4..6-px-sigma spots
- *                       (profiles/r03/refine_precision.txt): 64 px at upsample 10 / 20 / 40: 1.2e-5 / 2.3e-5 /
- *                       4.5e-5 px instead of 5.5e-5 / 1.3e-4 / 1.3e-4; and 14 % / 21 % fewer pairs per second at
- *                       upsample 10 / 20 (profiles/r03/bench_64_u10_refine_f64.json, bench_64_u20_refine_f64.json
- *                       next to bench.json, bench_64_u20.json).  Both are inside the 1e-3 px
- *                       this library promises; the flag buys the margin, not the promise.
- *                       Cutouts up to 32 px per side have no float64 form and are refined in float32 with either
- *                       value; upsample >= 43 on 33..85 px runs with ~50 spilled registers in this form (slower).
+ * Cutouts of 33..85 px per side (the 64 tile and its fold path) have two forms of that stage; up to 32 px it is
+ * float32, above 85 px float64, whatever `refine` says.
+ *   SPX_REFINE_DEFAULT  what spx_xcorr_refine_f32 / _f64 do: on 33..85 px float32 matrix products up to
+ *                       upsample 27 (two window blocks), float64 accumulation from upsample 28 on.
+ *   SPX_REFINE_F64      float64 accumulation at every upsample.
+ *   SPX_REFINE_F32      float32 at every upsample (the fastest; see below for what it gives up).
+ * Measured on one MI355X against the float64 definition (profiles/r03/refine_precision.txt, width_precision.txt;
+ * rates: bench_64_u*_refine_f64.json next to bench.json, bench_64_u20.json):
+ *   - 4..6-px-sigma spots, 64 px, upsample 10 / 20 / 40: float32 5.5e-5 / 1.3e-4 / 1.3e-4 px, float64 1.2e-5 /
+ *     2.3e-5 / 4.5e-5 px; float64 costs 14 % / 21 % of the pairs per second at upsample 10 / 20;
+ *   - the distance grows with the WIDTH of the spot (a flatter correlation peak on the fine grid).  Pairs beyond
+ *     1e-3 px, of 256 per (size 64 | 85 px, sigma band, upsample) cell, noise-free (width_precision_256.txt):
+ *       sigma <= 11 px   float32: 0 up to upsample 39, 0..3 at 59                        float64: 0
+ *       sigma 11..15 px  float32: 0 up to upsample 27, 5..6 at 39, 25..30 at 59          float64: 0
+ *       sigma 15..20 px  float32: 2..7 up to 27, 22..35 at 39, 47..89 at 59              float64: 0..3
+ *       sigma 20..25 px  (85 px) float32: 15..33 up to 27, 60 at 39, 111 at 59           float64: 0..15
+ *     So the default -- float32 up to upsample 27, float64 from 28 -- kept EVERY measured pair of spots up to
+ *     sigma = 15 px (FWHM ~ 35 px; wider ones fill a 33..85-px cutout) within 1e-3 px: 0 of 3072 below the switch,
+ *     0 of 2048 above it, where float32 would lose 2..12 %.  For wider spots neither form holds 1e-3 px for
+ *     every pair (float64: up to 6 % of the pairs at sigma 20..25 px / upsample 59, worst 4.4e-3 px).
+ * upsample >= 44 on 33..85 px runs with ~50 spilled registers in the float64 form (slower, correct).
  * Any other value: SPX_E_ARG.
  */
 #define SPX_REFINE_DEFAULT 0
 #define SPX_REFINE_F64 1
+#define SPX_REFINE_F32 2
 int spx_xcorr_refine_ex_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
                             int upsample, int cc_type, int refine, double* out_dxdy, int32_t* out_status,
                             void* workspace, size_t workspace_bytes, void* stream);

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SPX_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libsubpixal_hip.so')
 
 ABI_VERSION = 4
-REFINE_DEFAULT, REFINE_F64 = 0, 1         # SPX_REFINE_* (include/subpixal_hip.h)
+REFINE_DEFAULT, REFINE_F64, REFINE_F32 = 0, 1, 2         # SPX_REFINE_* (include/subpixal_hip.h)
 MAX_SIDE = 682
 MAX_UPSAMPLE = 59
 MAX_UPSAMPLE_GENERAL = 39      # cutouts above 128 px

@@ -42,6 +42,9 @@ def _input_dtype(*arrays):
     return torch.float64 if all(is64(a) for a in arrays) else torch.float32
 
 
+_REFINE_CODES = {'default': _ffi.REFINE_DEFAULT, 'float64': _ffi.REFINE_F64, 'float32': _ffi.REFINE_F32}
+
+
 def xcorr_refine_batch(ref, img, upsample=1, cc_type='CC', return_status=False, refine='default'):
     """Shifts of ``img[k]`` relative to ``ref[k]`` for a batch of cutout pairs.
 
@@ -54,18 +57,21 @@ def xcorr_refine_batch(ref, img, upsample=1, cc_type='CC', return_status=False, 
         ``upsample=2`` is the reference's half-pixel interlace (cc.py:121-126),
         ``upsample=1`` is ``fftconvolve(..,'same')`` + ``find_peak`` on one image.
 
-    refine : ``'default'`` or ``'float64'`` -- the arithmetic of that refinement (``SPX_REFINE_*``).  The
-        default is float32 matrix products on cutouts up to 85 px per side and float64 above; ``'float64'``
-        accumulates in float64 on 33..85 px as well: 4-7x closer to the float64 definition (64 px,
-        upsample 10: 1.2e-5 instead of 5.5e-5 px) for 14 % fewer pairs per second there -- both well inside
-        the 1e-3 px tolerance (``profiles/r03/refine_precision.txt``, ``bench_64_u10_refine_f64.json``).
-        Cutouts up to 32 px are refined in float32 either way.
+    refine : ``'default'``, ``'float64'`` or ``'float32'`` -- the arithmetic of that refinement on cutouts of
+        33..85 px per side (``SPX_REFINE_*``; up to 32 px it is float32, above 85 px float64 regardless).
+        ``'default'``: float32 matrix products up to upsample 27, float64 accumulation from 28 on.  float64 is
+        4-7x closer to the float64 definition (64 px, upsample 10: 1.2e-5 instead of 5.5e-5 px) for 14 %
+        (upsample 20: 21 %) fewer pairs per second.  The distance grows with the width of the spot: for spots
+        of sigma 11..15 px float32 loses no pair up to upsample 27 but 2 % / 10 % of them (beyond 1e-3 px) at
+        upsample 39 / 59, float64 none -- hence the default; spots wider than sigma 15 px (they fill such a
+        cutout) lose pairs in both forms, float64 far fewer (``profiles/r03/refine_precision.txt``,
+        ``width_precision_256.txt``, ``bench_64_u10_refine_f64.json``).
 
     Returns ``dxdy [N, 2]`` float64 (torch CUDA tensor if the inputs were
     tensors, else numpy) and, with ``return_status``, the int32 ``status [N]``.
     """
-    if refine not in ('default', 'float64'):
-        raise ValueError("refine must be 'default' or 'float64'.")
+    if refine not in _REFINE_CODES:
+        raise ValueError("refine must be 'default', 'float64' or 'float32'.")
     like_torch = isinstance(ref, torch.Tensor)
     dt = _input_dtype(ref, img)
     r = device.to_device(ref, dt)
@@ -81,7 +87,7 @@ def xcorr_refine_batch(ref, img, upsample=1, cc_type='CC', return_status=False, 
         fn = lib.spx_xcorr_refine_ex_f64 if dt == torch.float64 else lib.spx_xcorr_refine_ex_f32
         _ffi.check(fn(
             device.ptr(r), device.ptr(m), n, ny, nx, int(upsample), _cc_code(cc_type),
-            _ffi.REFINE_F64 if refine == 'float64' else _ffi.REFINE_DEFAULT,
+            _REFINE_CODES[refine],
             device.ptr(out), device.ptr(status), device.ptr(ws), ws_bytes, device.stream_ptr()))
     if return_status:
         return _finish(out, like_torch), _finish(status, like_torch)

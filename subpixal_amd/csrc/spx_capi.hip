@@ -158,11 +158,14 @@ int pair_tables_for(DeviceTables* t, Tile tile, int upsample, bool refine_f64, c
     return 0;
 }
 // what a call's `refine` argument means for the 64 tile (the other families have one form each: float32 on the
-// 32 tile, float64 above 85 px)
-int refine64_is_f64(int refine, bool* f64) {
-    if (refine != SPX_REFINE_DEFAULT && refine != SPX_REFINE_F64)
-        return fail(SPX_E_ARG, "refine must be SPX_REFINE_DEFAULT or SPX_REFINE_F64");
-    *f64 = refine == SPX_REFINE_F64 || spx::kRefine64DefaultF64;
+// 32 tile, float64 above 85 px).  The default follows the measurement in profiles/r03/width_precision_256.txt:
+// for spots up to sigma 15 px the float32 refine keeps every pair (0 of 3072) within 1e-3 px of the float64
+// definition up to two window blocks (upsample <= 27) and loses 2 % / 10 % of them at upsample 39 / 59, where the
+// float64 form loses none (0 of 2048); wider spots lose pairs in both forms, float64 far fewer.
+int refine64_is_f64(int refine, int wb, bool* f64) {
+    if (refine != SPX_REFINE_DEFAULT && refine != SPX_REFINE_F64 && refine != SPX_REFINE_F32)
+        return fail(SPX_E_ARG, "refine must be SPX_REFINE_DEFAULT, SPX_REFINE_F64 or SPX_REFINE_F32");
+    *f64 = refine == SPX_REFINE_F64 || (refine == SPX_REFINE_DEFAULT && (wb >= 3 || spx::kRefine64DefaultF64));
     return 0;
 }
 
@@ -480,7 +483,7 @@ int xcorr_refine(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
     if (nbatch < 0 || (nbatch > 0 && (!ref || !img || !out_dxdy)))
         return fail(SPX_E_ARG, "null pointer or negative batch");
     bool refine_f64 = false;
-    if (int rr = refine64_is_f64(refine, &refine_f64)) return rr;
+    if (int rr = refine64_is_f64(refine, spx::host::window_blocks(upsample), &refine_f64)) return rr;
     if (ny < 5 || nx < 5 || ny > SPX_MAX_SIDE || nx > SPX_MAX_SIDE)
         return fail(SPX_E_SHAPE, "pair mode supports cutouts of 5..682 pixels per side");
     const int wb = spx::host::window_blocks(upsample);

@@ -64,11 +64,12 @@ def test_argument_errors_without_gpu():
     assert lib.spx_find_displacement5_f32(p, p, 1, 128, 128, 0, p, None, p, None, 0, None) == -4
     assert lib.spx_find_peak_f64(p, None, None, 1, 8, 8, 0, 5, 0, 0, p, None, None) == -1
     assert lib.spx_xcorr_refine_f32(p, p, 0, 64, 64, 1, 0, p, None, None, 0, None) == 0   # empty batch
-    # the same entry with the refine arithmetic chosen per call (SPX_REFINE_DEFAULT = 0, SPX_REFINE_F64 = 1)
+    # the same entry with the refine arithmetic chosen per call (SPX_REFINE_DEFAULT = 0, SPX_REFINE_F64 = 1, SPX_REFINE_F32 = 2)
     for fn in (lib.spx_xcorr_refine_ex_f32, lib.spx_xcorr_refine_ex_f64):
         assert fn(p, p, 0, 64, 64, 10, 0, 0, p, None, None, 0, None) == 0               # empty batch, default
         assert fn(p, p, 0, 64, 64, 10, 0, 1, p, None, None, 0, None) == 0               # empty batch, float64 refine
-        assert fn(p, p, 0, 64, 64, 10, 0, 2, p, None, None, 0, None) == -1              # no such arithmetic
+        assert fn(p, p, 0, 64, 64, 10, 0, 2, p, None, None, 0, None) == 0               # empty batch, float32 refine
+        assert fn(p, p, 0, 64, 64, 10, 0, 3, p, None, None, 0, None) == -1              # no such arithmetic
         assert fn(p, p, 0, 64, 64, 10, 0, -1, p, None, None, 0, None) == -1
         assert fn(None, None, 1, 64, 64, 10, 0, 1, None, None, None, 0, None) == -1     # null pointers
         assert fn(p, p, 1, 683, 64, 10, 0, 1, p, None, None, 0, None) == -2             # shape

@@ -85,7 +85,7 @@ from subpixal_amd import synth
 from oracle import subpixal_oracle as orc
 for up, tol in ((1, 1e-5), (2, 2e-5), (10, 2e-4), (20, 2e-4)):
     ref, img, truth = datagen.pair_batch(21, 24, 64)
-    got, st = spx.xcorr_refine_batch(ref, img, upsample=up, return_status=True)
+    got, st = spx.xcorr_refine_batch(ref, img, upsample=up, return_status=True, refine='float32')   # (the eight-wave kernel has no float64 refine: the default would hand upsample >= 28 to the four-wave kernel)
     exp, est = orc.xcorr_refine_batch(ref, img, up)
     assert np.max(np.abs(got - exp)) < tol, (up, np.max(np.abs(got - exp)))
     assert np.array_equal(st, est)
@@ -96,7 +96,7 @@ for ny, nx, up, name in ((63, 61, 10, 'NCC'), (40, 57, 2, 'ZNCC'), (5, 5, 1, 'CC
         tx, ty = rng.uniform(-2, 2, 2) if min(ny, nx) > 8 else rng.uniform(-0.5, 0.5, 2)
         r[k], i[k] = datagen.pair_set(ny, nx, tx, ty, rng.uniform(1.2, min(ny, nx) / 8 + 1.2), 1.3, np.float32,
                                       noise_seed=int(rng.integers(1, 1000)), noise_level=0.01)
-    got, st = spx.xcorr_refine_batch(r, i, upsample=up, cc_type=name, return_status=True)
+    got, st = spx.xcorr_refine_batch(r, i, upsample=up, cc_type=name, return_status=True, refine='float32')
     exp, est = orc.xcorr_refine_batch(r, i, up, name)
     assert np.max(np.abs(got - exp)) < 3e-4 and np.array_equal(st, est), (ny, nx, up, name)
 ref, img, truth = synth.gaussian_pairs(30000, 64, seed=99)
@@ -176,7 +176,38 @@ def test_float64_refine_through_the_c_abi():
         ref, img, _ = datagen.pair_batch(7, 8, n)
         a = cc.xcorr_refine_batch(ref, img, upsample=10, refine='float64')
         b = cc.xcorr_refine_batch(ref, img, upsample=10)
-        assert np.array_equal(a, b), n
+        c = cc.xcorr_refine_batch(ref, img, upsample=10, refine='float32')
+        assert np.array_equal(a, b) and np.array_equal(a, c), n
     with pytest.raises(ValueError):
         cc.xcorr_refine_batch(ref, img, upsample=10, refine='float128')
+    # the default's rule on 33..85 px: float32 up to upsample 27 (two window blocks), float64 from 28 on
+    # (profiles/r03/width_precision.txt: where float32 starts to lose pairs of wide spots)
+    for n in (64, 80):
+        ref, img, _ = datagen.pair_batch(3, 8, n)
+        for up, same_as in ((10, 'float32'), (27, 'float32'), (28, 'float64'), (43, 'float64'), (59, 'float64')):
+            d = cc.xcorr_refine_batch(ref, img, upsample=up)
+            assert np.array_equal(d, cc.xcorr_refine_batch(ref, img, upsample=up, refine=same_as)), (n, up)
+            other = 'float64' if same_as == 'float32' else 'float32'
+            assert not np.array_equal(d, cc.xcorr_refine_batch(ref, img, upsample=up, refine=other)), (n, up)
 
+
+@pytest.mark.gpu
+def test_wide_spots_stay_within_tolerance_with_the_default_refine():
+    """What the default's change of form at upsample 28 is for (profiles/r03/width_precision_256.txt, 256 pairs per
+    cell): spots of sigma 11..15 px on the 64 tile and its fold path.  Measured: float32 refine 0 pairs beyond
+    1e-3 px of the float64 definition up to upsample 27, 2 % at 39, 10..12 % at 59 (worst 4.0e-3 px); float64
+    refine none (worst 5.3e-4 px).  (Spots wider than sigma 15 px fill such a cutout and lose pairs in both forms:
+    not asserted.)"""
+    from subpixal_amd import cc
+    for n in (64, 85):
+        tx, ty, sg, am = datagen.random_params(41, 64, n, sigma_lo=11.0, sigma_hi=15.0)
+        prs = [datagen.pair_set(n, n, tx[k], ty[k], sg[k], am[k]) for k in range(64)]
+        ref = np.stack([p[0] for p in prs]); img = np.stack([p[1] for p in prs])
+        for up in (27, 39, 59):
+            exp, est = orc.xcorr_refine_batch(ref, img, up)
+            got, st = cc.xcorr_refine_batch(ref, img, upsample=up, return_status=True)
+            assert np.array_equal(st, est)
+            assert np.abs(got - exp).max() < 1e-3, (n, up, np.abs(got - exp).max())
+        f32 = cc.xcorr_refine_batch(ref, img, upsample=59, refine='float32')
+        print('%d px, sigma 11..15 px, upsample 59: float32 refine %d of 64 pairs beyond 1e-3 px (worst %.2e), default %.2e'
+              % (n, int((np.abs(f32 - exp).max(axis=1) > 1e-3).sum()), np.abs(f32 - exp).max(), np.abs(got - exp).max()))

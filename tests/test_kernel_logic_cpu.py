@@ -54,7 +54,7 @@ def test_pair_mode_float64_refine():
                 assert d64 < 3e-5, (n, up, d64)
                 assert d64 < d32, (n, up, d64, d32)
     finally:
-        emu.set_refine64(0)
+        emu.set_refine64(-1)
 
 
 def test_pair_mode_eight_wave_kernel():

@@ -109,5 +109,5 @@ try:
             print('float64-refine pair %3dx%-3d U=%-2d max |d| %.2e' % (ny, nx, up, float(np.abs(got - exp).max())), flush=True)
             assert np.array_equal(st, est) and np.abs(got - exp).max() < 1e-4
 finally:
-    emu.set_refine64(0)
+    emu.set_refine64(-1)
 print('sanitizer cases OK')
