@@ -146,8 +146,17 @@ size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int nee
  *   out_status : int32   [nbatch]     SPX_ST_* ; may be NULL
  * 5 <= ny, nx <= SPX_MAX_SIDE (cutouts above 128 px take the slow general path: the reference's
  * cutouts, bounding box + padding of a segment, have no upper bound, cutout.py:159-175);
- * 1 <= upsample <= SPX_MAX_UPSAMPLE (cutouts above 128 px: <= SPX_MAX_UPSAMPLE_GENERAL -- their wide, flat
- * correlation peaks reached 1.2e-3 px against the float64 definition at upsample >= 40, past the 1e-3 px promised).
+ * 1 <= upsample <= SPX_MAX_UPSAMPLE (cutouts above 128 px: <= SPX_MAX_UPSAMPLE_GENERAL).
+ *
+ * Accuracy (the transforms are float32): the shift is within 1e-3 px of the float64 evaluation of the same
+ * definition (oracle/subpixal_oracle.py xcorr_refine) for Gaussian-like sources up to sigma = 15 px -- every pair
+ * measured, at every accepted size and upsample factor, noise-free and with 1 % noise; 3e-4 px and better for
+ * sigma 4..6 px (profiles/r03/refine_precision.txt, width_precision.txt, width_precision_256.txt,
+ * general_precision.txt).  It is NOT a bound for every content: the distance grows with the width of the
+ * correlation peak times the upsample factor, and sources wide enough to fill their cutout (sigma 15..25 px in
+ * 64..128 px) leave 1e-3 px for up to a few per cent of the pairs at upsample >= 39 (worst measured 4.4e-3 px).
+ * Above 128 px that happens from upsample 40 on even for cutout-sized margins (sigma 11..25 px in 200 px: 9.7e-4 px
+ * at upsample 39, 2.1e-3 at 59), which is why those cutouts take upsample <= SPX_MAX_UPSAMPLE_GENERAL.
  */
 int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
                          int upsample, int cc_type, double* out_dxdy, int32_t* out_status,
