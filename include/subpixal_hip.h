@@ -149,14 +149,16 @@ size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int nee
  * 1 <= upsample <= SPX_MAX_UPSAMPLE (cutouts above 128 px: <= SPX_MAX_UPSAMPLE_GENERAL).
  *
  * Accuracy (the transforms are float32): the shift is within 1e-3 px of the float64 evaluation of the same
- * definition (oracle/subpixal_oracle.py xcorr_refine) for Gaussian-like sources up to sigma = 15 px -- every pair
- * measured, at every accepted size and upsample factor, noise-free and with 1 % noise; 3e-4 px and better for
- * sigma 4..6 px (profiles/r03/refine_precision.txt, width_precision.txt, width_precision_256.txt,
- * general_precision.txt).  It is NOT a bound for every content: the distance grows with the width of the
- * correlation peak times the upsample factor, and sources wide enough to fill their cutout (sigma 15..25 px in
- * 64..128 px) leave 1e-3 px for up to a few per cent of the pairs at upsample >= 39 (worst measured 4.4e-3 px).
- * Above 128 px that happens from upsample 40 on even for cutout-sized margins (sigma 11..25 px in 200 px: 9.7e-4 px
- * at upsample 39, 2.1e-3 at 59), which is why those cutouts take upsample <= SPX_MAX_UPSAMPLE_GENERAL.
+ * definition (oracle/subpixal_oracle.py xcorr_refine) for sources that FIT their cutout: Gaussian sigma up to
+ * min(15 px, smaller side / 6), i.e. FWHM up to 0.4 of the side and 35 px -- every noise-free pair measured, on
+ * 24..200 px at upsample 20, 27, 39 and 59 (up to 39 above 128 px), with the default refine; 4.6e-4 px and better
+ * for sigma 4..6 px, which was also measured with 1 % noise (profiles/r03/width_precision_256.txt,
+ * width_precision_other_sizes.txt, width_precision.txt, refine_precision.txt, general_precision.txt).
+ * It is NOT a bound for every content: the distance grows with the width of the correlation peak times the
+ * upsample factor, and sources that fill their cutout leave 1e-3 px for some pairs -- sigma 8..11 px in 32 px:
+ * 1..2 of 128 at upsample >= 39; sigma 11..15 px in 48 px: 1 of 128 at upsample 20 and at 59; sigma 15..25 px in
+ * 64..128 px: up to 6 % at upsample 59 (worst measured 4.6e-3 px).  Above 128 px it happens from upsample 40 on
+ * for sigma 11..25 px (200 px: 9.7e-4 px at upsample 39, 2.1e-3 at 59): hence SPX_MAX_UPSAMPLE_GENERAL.
  */
 int spx_xcorr_refine_f32(const float* ref, const float* img, int64_t nbatch, int ny, int nx,
                          int upsample, int cc_type, double* out_dxdy, int32_t* out_status,
@@ -185,9 +187,9 @@ int spx_xcorr_refine_f64(const double* ref, const double* img, int64_t nbatch, i
  *       sigma 15..20 px  float32: 2..7 up to 27, 22..35 at 39, 47..89 at 59              float64: 0..3
  *       sigma 20..25 px  (85 px) float32: 15..33 up to 27, 60 at 39, 111 at 59           float64: 0..15
  *     So the default -- float32 up to upsample 27, float64 from 28 -- kept EVERY measured pair of spots up to
- *     sigma = 15 px (FWHM ~ 35 px; wider ones fill a 33..85-px cutout) within 1e-3 px: 0 of 3072 below the switch,
- *     0 of 2048 above it, where float32 would lose 2..12 %.  For wider spots neither form holds 1e-3 px for
- *     every pair (float64: up to 6 % of the pairs at sigma 20..25 px / upsample 59, worst 4.4e-3 px).
+ *     sigma = 15 px within 1e-3 px on 64 and 85 px: 0 of 3072 below the switch, 0 of 2048 above it, where float32
+ *     would lose 2..12 %.  For spots that fill the cutout neither form holds 1e-3 px for every pair (float64: up
+ *     to 6 % of the pairs at sigma 20..25 px / upsample 59, worst 4.4e-3 px; see the accuracy note above).
  * upsample >= 44 on 33..85 px runs with ~50 spilled registers in the float64 form (slower, correct).
  * Any other value: SPX_E_ARG.
  */
