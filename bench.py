@@ -78,8 +78,7 @@ def kernel_name(tile, upsample, refine='default'):
         return 'spx::pair32_kernel<%d, float>' % wb
     if tile <= 85:
         # the default refine arithmetic (float32) of the 64 tile; spx::RefineF64 is the SPX_REFINE_F64 form
-        # the library's default: float32 up to two window blocks (upsample <= 27), float64 from three on
-        f64 = wb > 0 and (refine == 'float64' or (refine == 'default' and wb >= 3))
+        f64 = wb > 0 and refine == 'float64'          # the library's default on 33..85 px is float32
         arith = 'RefineF64' if f64 else 'RefineF32'
         return 'spx::pair_kernel<2, %d, 0, %s, float, spx::%s>' % (wb, 'true' if tile > 64 else 'false', arith)
     return 'spx::pair128_kernel<3, %d, 0, float>' % wb

@@ -149,10 +149,12 @@ size_t spx_workspace_bytes_displacement5(int64_t nbatch, int ny, int nx, int nee
  * 1 <= upsample <= SPX_MAX_UPSAMPLE (cutouts above 128 px: <= SPX_MAX_UPSAMPLE_GENERAL).
  *
  * Accuracy (the transforms are float32): the shift is within 1e-3 px of the float64 evaluation of the same
- * definition (oracle/subpixal_oracle.py xcorr_refine) for sources that FIT their cutout: Gaussian sigma up to
- * min(15 px, smaller side / 6), i.e. FWHM up to 0.4 of the side and 35 px -- every noise-free pair measured, on
- * 24..200 px at upsample 20, 27, 39 and 59 (up to 39 above 128 px), with the default refine; 4.6e-4 px and better
- * for sigma 4..6 px, which was also measured with 1 % noise (profiles/r03/width_precision_256.txt,
+ * definition (oracle/subpixal_oracle.py xcorr_refine) for sources that FIT their cutout -- Gaussian sigma up to
+ * min(15 px, smaller side / 6), i.e. FWHM up to 0.4 of the side and 35 px -- on 24..200 px: every noise-free pair
+ * measured, at upsample up to 27 with the default refine, and at upsample 28..59 (up to 39 above 128 px) with
+ * SPX_REFINE_F64 on 33..85 px (above 85 px the refine is float64 anyway); there the default (float32) refine
+ * covers sigma <= 11 px up to upsample 39 and sigma <= 8 px up to 59 (spx_xcorr_refine_ex_* below).  4.6e-4 px
+ * and better for sigma 4..6 px at any upsample in either form, which was also measured with 1 % noise (profiles/r03/width_precision_256.txt,
  * width_precision_other_sizes.txt, width_precision.txt, refine_precision.txt, general_precision.txt).
  * It is NOT a bound for every content: the distance grows with the width of the correlation peak times the
  * upsample factor, and sources that fill their cutout leave 1e-3 px for some pairs -- sigma 8..11 px in 32 px:
@@ -172,25 +174,27 @@ int spx_xcorr_refine_f64(const double* ref, const double* img, int64_t nbatch, i
  * upsample > 1) chosen by the caller.  The transforms are float32 either way.
  * Cutouts of 33..85 px per side (the 64 tile and its fold path) have two forms of that stage; up to 32 px it is
  * float32, above 85 px float64, whatever `refine` says.
- *   SPX_REFINE_DEFAULT  what spx_xcorr_refine_f32 / _f64 do: on 33..85 px float32 matrix products up to
- *                       upsample 27 (two window blocks), float64 accumulation from upsample 28 on.
- *   SPX_REFINE_F64      float64 accumulation at every upsample.
- *   SPX_REFINE_F32      float32 at every upsample (the fastest; see below for what it gives up).
- * Measured on one MI355X against the float64 definition (profiles/r03/refine_precision.txt, width_precision.txt;
- * rates: bench_64_u*_refine_f64.json next to bench.json, bench_64_u20.json):
+ *   SPX_REFINE_DEFAULT  what spx_xcorr_refine_f32 / _f64 do: float32 matrix products (= SPX_REFINE_F32).
+ *   SPX_REFINE_F64      float64 accumulation: closer to the definition, a wider accuracy domain, slower.
+ *   SPX_REFINE_F32      float32, said explicitly.
+ * Measured on one MI355X against the float64 definition (profiles/r03/refine_precision.txt, width_precision_256.txt;
+ * rates: bench_64_u*_refine_f64.json next to bench.json, bench_64_u20.json; default_rule_cost.txt):
  *   - 4..6-px-sigma spots, 64 px, upsample 10 / 20 / 40: float32 5.5e-5 / 1.3e-4 / 1.3e-4 px, float64 1.2e-5 /
- *     2.3e-5 / 4.5e-5 px; float64 costs 14 % / 21 % of the pairs per second at upsample 10 / 20;
+ *     2.3e-5 / 4.5e-5 px; float64 costs 14 % / 21 % of the pairs per second at upsample 10 / 20 and about half of
+ *     them from upsample 28 on (12.0 instead of 6.2 ms per 1e5 pairs at 28..43, 26.3 instead of 11.9 at 59: 336 /
+ *     512 float64 MFMAs per wave instead of 80; from upsample 44 also ~50 spilled registers);
  *   - the distance grows with the WIDTH of the spot (a flatter correlation peak on the fine grid).  Pairs beyond
- *     1e-3 px, of 256 per (size 64 | 85 px, sigma band, upsample) cell, noise-free (width_precision_256.txt):
+ *     1e-3 px, of 256 per (size 64 | 85 px, sigma band, upsample) cell, noise-free:
  *       sigma <= 11 px   float32: 0 up to upsample 39, 0..3 at 59                        float64: 0
  *       sigma 11..15 px  float32: 0 up to upsample 27, 5..6 at 39, 25..30 at 59          float64: 0
  *       sigma 15..20 px  float32: 2..7 up to 27, 22..35 at 39, 47..89 at 59              float64: 0..3
  *       sigma 20..25 px  (85 px) float32: 15..33 up to 27, 60 at 39, 111 at 59           float64: 0..15
- *     So the default -- float32 up to upsample 27, float64 from 28 -- kept EVERY measured pair of spots up to
- *     sigma = 15 px within 1e-3 px on 64 and 85 px: 0 of 3072 below the switch, 0 of 2048 above it, where float32
- *     would lose 2..12 %.  For spots that fill the cutout neither form holds 1e-3 px for every pair (float64: up
- *     to 6 % of the pairs at sigma 20..25 px / upsample 59, worst 4.4e-3 px; see the accuracy note above).
- * upsample >= 44 on 33..85 px runs with ~50 spilled registers in the float64 form (slower, correct).
+ *     So float32 (the default) kept every measured pair within 1e-3 px for sigma <= 11 px up to upsample 39 and
+ *     for sigma <= 15 px up to upsample 27; float64 for sigma <= 15 px at every upsample.  A caller who refines
+ *     wide sources on very fine grids (sigma 11..15 px at upsample >= 28) asks for SPX_REFINE_F64 and pays the
+ *     factor two; making that the default for everybody was tried and withdrawn once its cost was measured.
+ *     For spots that fill the cutout neither form holds 1e-3 px for every pair (float64: up to 6 % of the pairs
+ *     at sigma 20..25 px / upsample 59, worst 4.4e-3 px; see the accuracy note above).
  * Any other value: SPX_E_ARG.
  */
 #define SPX_REFINE_DEFAULT 0

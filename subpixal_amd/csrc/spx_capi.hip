@@ -158,14 +158,17 @@ int pair_tables_for(DeviceTables* t, Tile tile, int upsample, bool refine_f64, c
     return 0;
 }
 // what a call's `refine` argument means for the 64 tile (the other families have one form each: float32 on the
-// 32 tile, float64 above 85 px).  The default follows the measurement in profiles/r03/width_precision_256.txt:
-// for spots up to sigma 15 px the float32 refine keeps every pair (0 of 3072) within 1e-3 px of the float64
-// definition up to two window blocks (upsample <= 27) and loses 2 % / 10 % of them at upsample 39 / 59, where the
-// float64 form loses none (0 of 2048); wider spots lose pairs in both forms, float64 far fewer.
+// 32 tile, float64 above 85 px).  The default is float32 at every upsample.  A rule "float64 from three window
+// blocks on" was in for an hour of round 3 -- float32 loses 2 % / 10 % of the pairs of sigma 11..15 px spots at
+// upsample 39 / 59, float64 none (profiles/r03/width_precision_256.txt) -- until its cost was measured: the
+// float64 form takes 12.0 instead of 6.2 ms per 1e5 pairs at upsample 28..43 and 26.3 instead of 11.9 at 59
+// (profiles/r03/default_rule_cost.txt: 336 / 512 float64 MFMAs per wave instead of 80).  Halving every such call's
+// rate to cover that corner is the caller's decision, not a default: SPX_REFINE_F64.
 int refine64_is_f64(int refine, int wb, bool* f64) {
+    (void)wb;
     if (refine != SPX_REFINE_DEFAULT && refine != SPX_REFINE_F64 && refine != SPX_REFINE_F32)
         return fail(SPX_E_ARG, "refine must be SPX_REFINE_DEFAULT, SPX_REFINE_F64 or SPX_REFINE_F32");
-    *f64 = refine == SPX_REFINE_F64 || (refine == SPX_REFINE_DEFAULT && (wb >= 3 || spx::kRefine64DefaultF64));
+    *f64 = refine == SPX_REFINE_F64 || (refine == SPX_REFINE_DEFAULT && spx::kRefine64DefaultF64);
     return 0;
 }
 

@@ -29,8 +29,8 @@ extern "C" int emu_lds_bytes(int U) {
 #if EMU_PART == 4
 int64_t g_grid = 0;            // 0: one workgroup per item; else grid-stride over the batch
 extern "C" void emu_set_grid(int64_t g) { g_grid = g; }
-int g_refine64 = -1;           // the 64 tile's refine: -1 the product's default rule (float32 up to two window
-                               // blocks, float64 from three: spx_capi.hip refine64_is_f64), 0 float32, 1 float64
+int g_refine64 = -1;           // the 64 tile's refine: -1 the product's default (float32: spx_capi.hip
+                               // refine64_is_f64), 0 float32, 1 float64
 extern "C" void emu_set_refine64(int v) { g_refine64 = v; }
 // the kernels' workgroup -> first item mapping (spx_kernels.h), for the bijection test
 extern "C" int64_t emu_first_item(int64_t b, int64_t nwg) { return first_item(b, nwg); }
@@ -71,7 +71,7 @@ static int emu_pair64_as(const TIn* ref, const TIn* img, int64_t nbatch, int ny,
 template <bool FOLD, typename TIn>
 static int emu_pair64(const TIn* ref, const TIn* img, int64_t nbatch, int ny, int nx,
                       int U, int cc_type, double* out, int* status) {
-    const bool f64 = g_refine64 < 0 ? host::window_blocks(U) >= 3 : g_refine64 != 0;
+    const bool f64 = g_refine64 > 0;
     return f64 ? emu_pair64_as<FOLD, TIn, RefineF64>(ref, img, nbatch, ny, nx, U, cc_type, out, status)
                : emu_pair64_as<FOLD, TIn, RefineF32>(ref, img, nbatch, ny, nx, U, cc_type, out, status);
 }

@@ -39,8 +39,8 @@ def set_grid(g):
 
 
 def set_refine64(v):
-    """refine arithmetic of the 64 tile and its fold path in pair(): -1 the product's default rule (float32 up to
-    upsample 27, float64 from 28: SPX_REFINE_DEFAULT), 0 float32 (SPX_REFINE_F32), 1 float64 (SPX_REFINE_F64)"""
+    """refine arithmetic of the 64 tile and its fold path in pair(): -1 the product's default (float32:
+    SPX_REFINE_DEFAULT), 0 float32 (SPX_REFINE_F32), 1 float64 (SPX_REFINE_F64)"""
     lib().emu_set_refine64(int(v))
 
 

@@ -180,34 +180,42 @@ def test_float64_refine_through_the_c_abi():
         assert np.array_equal(a, b) and np.array_equal(a, c), n
     with pytest.raises(ValueError):
         cc.xcorr_refine_batch(ref, img, upsample=10, refine='float128')
-    # the default's rule on 33..85 px: float32 up to upsample 27 (two window blocks), float64 from 28 on
-    # (profiles/r03/width_precision.txt: where float32 starts to lose pairs of wide spots)
+    # the default on 33..85 px is the float32 form at every upsample (spx_capi.hip refine64_is_f64: why)
     for n in (64, 80):
         ref, img, _ = datagen.pair_batch(3, 8, n)
-        for up, same_as in ((10, 'float32'), (27, 'float32'), (28, 'float64'), (43, 'float64'), (59, 'float64')):
+        for up in (10, 27, 28, 43, 59):
             d = cc.xcorr_refine_batch(ref, img, upsample=up)
-            assert np.array_equal(d, cc.xcorr_refine_batch(ref, img, upsample=up, refine=same_as)), (n, up)
-            other = 'float64' if same_as == 'float32' else 'float32'
-            assert not np.array_equal(d, cc.xcorr_refine_batch(ref, img, upsample=up, refine=other)), (n, up)
+            assert np.array_equal(d, cc.xcorr_refine_batch(ref, img, upsample=up, refine='float32')), (n, up)
+            assert not np.array_equal(d, cc.xcorr_refine_batch(ref, img, upsample=up, refine='float64')), (n, up)
 
 
 @pytest.mark.gpu
-def test_wide_spots_stay_within_tolerance_with_the_default_refine():
-    """What the default's change of form at upsample 28 is for (profiles/r03/width_precision_256.txt, 256 pairs per
-    cell): spots of sigma 11..15 px on the 64 tile and its fold path.  Measured: float32 refine 0 pairs beyond
-    1e-3 px of the float64 definition up to upsample 27, 2 % at 39, 10..12 % at 59 (worst 4.0e-3 px); float64
-    refine none (worst 5.3e-4 px).  (Spots wider than sigma 15 px fill such a cutout and lose pairs in both forms:
-    not asserted.)"""
+def test_wide_spots_and_the_two_refine_forms():
+    """The accuracy domain of each refine form on the 64 tile and its fold path, as include/subpixal_hip.h states it
+    (profiles/r03/width_precision_256.txt, 256 pairs per cell): spots of sigma 8..11 px are within 1e-3 px of the
+    float64 definition in the DEFAULT (float32) form up to upsample 39; spots of sigma 11..15 px are in the float32
+    form up to upsample 27 only (2 % beyond at 39, 10..12 % at 59, worst 4.0e-3 px) and in the float64 form at every
+    upsample (worst 5.3e-4 px).  (Sources that fill their cutout, sigma > side / 6, lose pairs in both: not asserted.)"""
     from subpixal_amd import cc
+    def spots(n, lo, hi, count=64):
+        tx, ty, sg, am = datagen.random_params(41, count, n, sigma_lo=lo, sigma_hi=hi)
+        prs = [datagen.pair_set(n, n, tx[k], ty[k], sg[k], am[k]) for k in range(count)]
+        return np.stack([p[0] for p in prs]), np.stack([p[1] for p in prs])
     for n in (64, 85):
-        tx, ty, sg, am = datagen.random_params(41, 64, n, sigma_lo=11.0, sigma_hi=15.0)
-        prs = [datagen.pair_set(n, n, tx[k], ty[k], sg[k], am[k]) for k in range(64)]
-        ref = np.stack([p[0] for p in prs]); img = np.stack([p[1] for p in prs])
-        for up in (27, 39, 59):
+        ref, img = spots(n, 8.0, 11.0)
+        for up in (20, 39):
             exp, est = orc.xcorr_refine_batch(ref, img, up)
             got, st = cc.xcorr_refine_batch(ref, img, upsample=up, return_status=True)
-            assert np.array_equal(st, est)
+            assert np.array_equal(st, est) and np.abs(got - exp).max() < 1e-3, (n, up, np.abs(got - exp).max())
+        ref, img = spots(n, 11.0, 15.0)
+        for up in (20, 27):
+            exp, est = orc.xcorr_refine_batch(ref, img, up)
+            got = cc.xcorr_refine_batch(ref, img, upsample=up)
             assert np.abs(got - exp).max() < 1e-3, (n, up, np.abs(got - exp).max())
-        f32 = cc.xcorr_refine_batch(ref, img, upsample=59, refine='float32')
-        print('%d px, sigma 11..15 px, upsample 59: float32 refine %d of 64 pairs beyond 1e-3 px (worst %.2e), default %.2e'
+        for up in (39, 59):
+            exp, est = orc.xcorr_refine_batch(ref, img, up)
+            got, st = cc.xcorr_refine_batch(ref, img, upsample=up, return_status=True, refine='float64')
+            assert np.array_equal(st, est) and np.abs(got - exp).max() < 1e-3, (n, up, np.abs(got - exp).max())
+        f32 = cc.xcorr_refine_batch(ref, img, upsample=59)
+        print('%d px, sigma 11..15 px, upsample 59: float32 (default) %d of 64 pairs beyond 1e-3 px (worst %.2e), float64 worst %.2e'
               % (n, int((np.abs(f32 - exp).max(axis=1) > 1e-3).sum()), np.abs(f32 - exp).max(), np.abs(got - exp).max()))
