@@ -1422,89 +1422,47 @@ SPX_DEVICE void fine_window(unsigned char* lds, const FineTables<WB, R>& ft,
             else { if (c == 0) fbuf[b * W + a] = val; else fbuf[b * W + a] += val; }
         }
     };
-    // all WB x WB result tiles live at once: float32 always; float64 up to two window blocks (0 spills, and at
-    // upsample 20 measured 6.0 ms per 1e5 pairs against 7.6 ms for the block-at-a-time form below, whose table
-    // reads from L2 sit in a serial loop: profiles/r03/refine64_throughput_ab.txt, bench_64_u20_refine_f64.json)
-    if constexpr (sizeof(S) == 4 || WB <= 2) {
-        V4 f[WB][WB];
+    // All WB x WB result tiles live at once, in both arithmetic types.  For float64 a block-at-a-time stage 2 (as
+    // fine_window128: only WB result tiles live) was built to keep the accumulators inside the register file and
+    // measured slower at EVERY window size although it spills less -- its table reads from L2 sit in a serial loop:
+    // two blocks 7.6 vs 6.0 ms per 1e5 pairs (0 spills either way), three 12.0 vs 8.8 ms (0 vs 2..7 spilled
+    // registers), four 26.2 vs 19.7 ms (~52 vs ~143) -- profiles/r03/f64_live3_ab.txt, f64_live4_ab.txt.
+    V4 f[WB][WB];
 #pragma unroll
-        for (int bb = 0; bb < WB; ++bb)
+    for (int bb = 0; bb < WB; ++bb)
 #pragma unroll
-            for (int ab = 0; ab < WB; ++ab) f[bb][ab] = R::zero();
+        for (int ab = 0; ab < WB; ++ab) f[bb][ab] = R::zero();
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            V4 ka[WB];
+    for (int t = 0; t < 4; ++t) {
+        V4 ka[WB];
 #pragma unroll
-            for (int bb = 0; bb < WB; ++bb) ka[bb] = ft.x(bb, t);
+        for (int bb = 0; bb < WB; ++bb) ka[bb] = ft.x(bb, t);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = lxc + 16 * t + R::drow(lk, r) - 32;
-                const S sgn = (cx && ((m >> 6) & 1)) ? (S)-1 : (S)1;
-#pragma unroll
-                for (int bb = 0; bb < WB; ++bb)
-#pragma unroll
-                    for (int ab = 0; ab < WB; ++ab)
-                        f[bb][ab] = R::mma(sgn * ka[bb][r], acc[ab][t][r], f[bb][ab]);
-            }
-        }
-        if constexpr (L::fb_count(W) == C * C) {
+        for (int r = 0; r < 4; ++r) {
+            const int m = lxc + 16 * t + R::drow(lk, r) - 32;
+            const S sgn = (cx && ((m >> 6) & 1)) ? (S)-1 : (S)1;
 #pragma unroll
             for (int bb = 0; bb < WB; ++bb)
 #pragma unroll
-                for (int ab = 0; ab < WB; ++ab) put(bb, ab, f[bb][ab], 0);
-            rt::block_sync_lds();
-        } else {
-            for (int c = 0; c < C * C; ++c) {
-                if (wave == c) {
-#pragma unroll
-                    for (int bb = 0; bb < WB; ++bb)
-#pragma unroll
-                        for (int ab = 0; ab < WB; ++ab) put(bb, ab, f[bb][ab], c);
-                }
-                rt::block_sync_lds();
-            }
+                for (int ab = 0; ab < WB; ++ab)
+                    f[bb][ab] = R::mma(sgn * ka[bb][r], acc[ab][t][r], f[bb][ab]);
         }
+    }
+    if constexpr (L::fb_count(W) == C * C) {
+#pragma unroll
+        for (int bb = 0; bb < WB; ++bb)
+#pragma unroll
+            for (int ab = 0; ab < WB; ++ab) put(bb, ab, f[bb][ab], 0);
+        rt::block_sync_lds();
     } else {
-        // float64, three and four window blocks: one block of fine x offsets at a time (as fine_window128), so that
-        // only WB result tiles of eight registers are live beside stage 1's 4 WB (four blocks: 160 registers, not 256).
-        // Large windows: the classes take turns block by block, still in fixed order.
-        auto block = [&](int bb, V4 (&f)[WB]) {
+        for (int c = 0; c < C * C; ++c) {
+            if (wave == c) {
 #pragma unroll
-            for (int ab = 0; ab < WB; ++ab) f[ab] = R::zero();
+                for (int bb = 0; bb < WB; ++bb)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const V4 ka = ft.x(bb, t);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = lxc + 16 * t + R::drow(lk, r) - 32;
-                    const S sgn = (cx && ((m >> 6) & 1)) ? (S)-1 : (S)1;
-#pragma unroll
-                    for (int ab = 0; ab < WB; ++ab) f[ab] = R::mma(sgn * ka[r], acc[ab][t][r], f[ab]);
-                }
-            }
-        };
-        if constexpr (L::fb_count(W) == C * C) {
-#pragma unroll
-            for (int bb = 0; bb < WB; ++bb) {
-                V4 f[WB];
-                block(bb, f);
-#pragma unroll
-                for (int ab = 0; ab < WB; ++ab) put(bb, ab, f[ab], 0);
+                    for (int ab = 0; ab < WB; ++ab) put(bb, ab, f[bb][ab], c);
             }
             rt::block_sync_lds();
-        } else {
-            for (int c = 0; c < C * C; ++c) {
-                if (wave == c) {
-#pragma unroll
-                    for (int bb = 0; bb < WB; ++bb) {
-                        V4 f[WB];
-                        block(bb, f);
-#pragma unroll
-                        for (int ab = 0; ab < WB; ++ab) put(bb, ab, f[ab], c);
-                    }
-                }
-                rt::block_sync_lds();
-            }
         }
     }
 }
