@@ -180,9 +180,10 @@ int spx_xcorr_refine_f64(const double* ref, const double* img, int64_t nbatch, i
  * Measured on one MI355X against the float64 definition (profiles/r03/refine_precision.txt, width_precision_256.txt;
  * rates: bench_64_u*_refine_f64.json next to bench.json, bench_64_u20.json; default_rule_cost.txt):
  *   - 4..6-px-sigma spots, 64 px, upsample 10 / 20 / 40: float32 5.5e-5 / 1.3e-4 / 1.3e-4 px, float64 1.2e-5 /
- *     2.3e-5 / 4.5e-5 px; float64 costs 14 % / 21 % of the pairs per second at upsample 10 / 20 and about half of
- *     them from upsample 28 on (12.0 instead of 6.2 ms per 1e5 pairs at 28..43, 26.3 instead of 11.9 at 59: 336 /
- *     512 float64 MFMAs per wave instead of 80; from upsample 44 also ~50 spilled registers);
+ *     2.3e-5 / 4.5e-5 px; float64 costs 14 % / 21 % of the pairs per second at upsample 10 / 20, 29 % at 28..43
+ *     (8.8 instead of 6.2 ms per 1e5 pairs) and 40 % from 44 on (19.7 instead of 11.9 ms at 59): 336 / 512 float64
+ *     MFMAs per wave instead of 80, and 2..7 / ~143 spilled registers at three / four window blocks
+ *     (f64_live3_ab.txt, f64_live4_ab.txt: the form that spills less was slower);
  *   - the distance grows with the WIDTH of the spot (a flatter correlation peak on the fine grid).  Pairs beyond
  *     1e-3 px, of 256 per (size 64 | 85 px, sigma band, upsample) cell, noise-free:
  *       sigma <= 11 px   float32: 0 up to upsample 39, 0..3 at 59                        float64: 0
@@ -192,7 +193,7 @@ int spx_xcorr_refine_f64(const double* ref, const double* img, int64_t nbatch, i
  *     So float32 (the default) kept every measured pair within 1e-3 px for sigma <= 11 px up to upsample 39 and
  *     for sigma <= 15 px up to upsample 27; float64 for sigma <= 15 px at every upsample.  A caller who refines
  *     wide sources on very fine grids (sigma 11..15 px at upsample >= 28) asks for SPX_REFINE_F64 and pays the
- *     factor two; making that the default for everybody was tried and withdrawn once its cost was measured.
+ *     29..40 %; making that the default for everybody was tried and withdrawn once its cost was measured.
  *     For spots that fill the cutout neither form holds 1e-3 px for every pair (float64: up to 6 % of the pairs
  *     at sigma 20..25 px / upsample 59, worst 4.4e-3 px; see the accuracy note above).
  * Any other value: SPX_E_ARG.

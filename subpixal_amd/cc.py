@@ -61,7 +61,7 @@ def xcorr_refine_batch(ref, img, upsample=1, cc_type='CC', return_status=False, 
         33..85 px per side (``SPX_REFINE_*``; up to 32 px it is float32, above 85 px float64 regardless).
         ``'default'`` is float32 matrix products.  float64 accumulation is 4-7x closer to the float64
         definition (64 px, upsample 10: 1.2e-5 instead of 5.5e-5 px) for 14 % (upsample 20: 21 %, upsample
-        28 and above: ~50 %) fewer pairs per second.  The distance grows with the width of the spot: for spots
+        28 and above: 29..40 %) fewer pairs per second.  The distance grows with the width of the spot: for spots
         of sigma 11..15 px float32 loses no pair up to upsample 27 but 2 % / 10 % of them (beyond 1e-3 px) at
         upsample 39 / 59, float64 none -- ask for ``'float64'`` there; spots that fill their cutout (sigma beyond
         min(15 px, side / 6)) lose some pairs in both forms, float64 far fewer (``profiles/r03/refine_precision.txt``,

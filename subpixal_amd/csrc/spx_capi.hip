@@ -162,8 +162,9 @@ int pair_tables_for(DeviceTables* t, Tile tile, int upsample, bool refine_f64, c
 // blocks on" was in for an hour of round 3 -- float32 loses 2 % / 10 % of the pairs of sigma 11..15 px spots at
 // upsample 39 / 59, float64 none (profiles/r03/width_precision_256.txt) -- until its cost was measured: the
 // float64 form takes 12.0 instead of 6.2 ms per 1e5 pairs at upsample 28..43 and 26.3 instead of 11.9 at 59
-// (profiles/r03/default_rule_cost.txt: 336 / 512 float64 MFMAs per wave instead of 80).  Halving every such call's
-// rate to cover that corner is the caller's decision, not a default: SPX_REFINE_F64.
+// (profiles/r03/default_rule_cost.txt: 336 / 512 float64 MFMAs per wave instead of 80; since brought to 8.8 and
+// 19.7 ms, f64_live3_ab.txt / f64_live4_ab.txt).  Taking 29..40 % off every such call's rate to cover that corner is
+// the caller's decision, not a default: SPX_REFINE_F64.
 int refine64_is_f64(int refine, int wb, bool* f64) {
     (void)wb;
     if (refine != SPX_REFINE_DEFAULT && refine != SPX_REFINE_F64 && refine != SPX_REFINE_F32)
