@@ -180,6 +180,16 @@ def test_float64_refine_through_the_c_abi():
         assert np.array_equal(a, b) and np.array_equal(a, c), n
     with pytest.raises(ValueError):
         cc.xcorr_refine_batch(ref, img, upsample=10, refine='float128')
+    # float64 cutouts (spx_xcorr_refine_ex_f64) take the same two forms
+    for n in (64, 80):
+        ref, img, _ = datagen.pair_batch(20261005 + n, 12, n, dtype=np.float64)
+        for up in (10, 28):
+            exp, est = orc.xcorr_refine_batch(ref, img, up)
+            got64, st64 = cc.xcorr_refine_batch(ref, img, upsample=up, return_status=True, refine='float64')
+            got32 = cc.xcorr_refine_batch(ref, img, upsample=up)
+            assert np.array_equal(st64, est)
+            assert np.abs(got64 - exp).max() < 6e-5 and np.abs(got32 - exp).max() < 3e-4, (n, up)
+            assert np.abs(got64 - exp).max() < np.abs(got32 - exp).max(), (n, up)
     # the default on 33..85 px is the float32 form at every upsample (spx_capi.hip refine64_is_f64: why)
     for n in (64, 80):
         ref, img, _ = datagen.pair_batch(3, 8, n)
